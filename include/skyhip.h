@@ -1,0 +1,121 @@
+/*
+ * skyhip.h -- C ABI of libskyhip.so, the MI355X (gfx950) chunk-processing stage for the Skyplane gateway.
+ *
+ * The reference (skyplane-project/skyplane v0.3.2) is pure Python and has NO FFI for this path; the calls
+ * below are what a ctypes binding inside the reference would replace (see INTEGRATION.md for that stub):
+ *
+ *   skyhip_process_batch / skyhip_process_device
+ *       -> `data = lz4.frame.compress(data)`           skyplane/gateway/operators/gateway_operator.py:358-361
+ *       -> `hashlib.md5()` / `.update()` / `.digest()`  skyplane/obj_store/s3_interface.py:181-192 (and the
+ *          gcs/azure/cos/scp siblings), requested by `generate_md5=True` at gateway_operator.py:555-565;
+ *          the digest is what Chunk.md5_hash (skyplane/chunk.py:21) is declared to carry.
+ *       -> (new, not in the reference) Gear content-defined cut points, per-segment fingerprints and the
+ *          on-GPU dedup table named by BASELINE.json's north_star.
+ *   skyhip_frame_bound
+ *       -> the size a receiver must be prepared to read: WireProtocolHeader.data_len (skyplane/chunk.py:99).
+ *
+ * Contract: plain pointers and sizes only; one context per worker process, created AFTER
+ * fork, used from one thread at a time; calls are synchronous; every entry point returns 0 on success or
+ * a negative SKYHIP_E_* code -- no exceptions, no aborts, output buffers are not to be trusted on failure.
+ * The frames produced decode with lz4.frame.decompress (gateway_receiver.py:195-201) to the input bytes;
+ * digests equal hashlib.md5(raw).digest().  There is NO CPU fallback inside this library.
+ */
+#ifndef SKYHIP_H
+#define SKYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKYHIP_ABI_VERSION 1
+
+/* flags for process_batch / process_device */
+#define SKYHIP_F_LZ4   0x1u   /* emit an LZ4 frame per chunk */
+#define SKYHIP_F_MD5   0x2u   /* emit the RFC 1321 digest of each chunk's raw bytes */
+#define SKYHIP_F_CDC   0x4u   /* emit Gear content-defined cut points (+ per-segment MD5 fingerprints) */
+#define SKYHIP_F_DEDUP 0x8u   /* look the fingerprints up in / insert them into the context's dedup table */
+
+/* error codes (all negative) */
+#define SKYHIP_OK            0
+#define SKYHIP_E_INVAL      -1   /* bad argument */
+#define SKYHIP_E_NOMEM      -2   /* hipMalloc / hipHostMalloc failed */
+#define SKYHIP_E_HIP        -3   /* a HIP runtime call or kernel launch failed (see skyhip_last_hip_error) */
+#define SKYHIP_E_TOOBIG     -4   /* chunk larger than max_chunk_bytes / batch larger than supported */
+#define SKYHIP_E_CAP        -5   /* an output buffer is smaller than skyhip_frame_bound(len) / cut capacity */
+#define SKYHIP_E_NODEVICE   -6   /* no usable gfx950 device */
+#define SKYHIP_E_TABLEFULL  -7   /* dedup table is full */
+
+typedef struct skyhip_ctx skyhip_ctx;   /* opaque: owns device scratch, streams, events, dedup table */
+
+/* Per-kernel device time (HIP events on the library's own streams) accumulated since the last reset. */
+typedef struct skyhip_timing {
+    double lz4_ms;        /* sky_lz4_compress: the dominant kernel */
+    double layout_ms;     /* sky_frame_layout */
+    double gather_ms;     /* sky_frame_gather */
+    double md5_ms;        /* sky_md5_chunks */
+    double cdc_ms;        /* gear candidate + cut selection + segment fingerprints + dedup */
+    uint64_t lz4_launches;
+    uint64_t lz4_in_bytes;   /* raw bytes the LZ4 kernel consumed */
+    uint64_t lz4_out_bytes;  /* bytes it wrote to its block slots... (frame bytes incl. headers) */
+    uint64_t md5_launches;
+    uint64_t md5_in_bytes;
+} skyhip_timing;
+
+int  skyhip_abi_version(void);
+
+/* device_id: HIP ordinal.  max_chunk_bytes: largest chunk a call may contain (<= 1 GiB).
+ * max_batch: number of chunks whose LZ4 scratch is resident at once; larger batches are processed in
+ * sub-batches of this size (MD5 always runs over the whole batch in one launch). */
+int  skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_ctx** out);
+void skyhip_destroy(skyhip_ctx* ctx);
+
+/* Worst-case LZ4 frame size for raw_len input bytes: 15-byte header + 4 bytes per 64 KiB block + raw + 4. */
+size_t skyhip_frame_bound(size_t raw_len);
+
+/* Host-buffer batch (what the gateway operator calls).  Caller owns every buffer; pinned memory is
+ * faster but not required.  in[i]/in_len[i]: raw chunk bytes.  out[i]/out_cap[i]: where chunk i's LZ4
+ * frame goes (cap >= skyhip_frame_bound(in_len[i])); out_len[i] receives the frame size.
+ * md5[i]: 16-byte digest.  cuts[i]/cuts_cap[i]/n_cuts[i]: optional CDC END offsets (NULL to skip). */
+int  skyhip_process_batch(skyhip_ctx* ctx, int n,
+                          const uint8_t* const* in, const size_t* in_len,
+                          uint8_t* const* out, const size_t* out_cap, size_t* out_len,
+                          uint8_t (*md5)[16],
+                          uint32_t* const* cuts, const size_t* cuts_cap, size_t* n_cuts,
+                          uint32_t flags);
+
+/* Device-resident batch (kernel-only path: inputs already in HBM, PCIe excluded).
+ * d_in / d_out are DEVICE pointers on ctx's device; in_off/in_len/out_off/out_cap are HOST arrays of
+ * byte offsets into d_in / d_out.  out_len (host, may be NULL) and md5 (host, may be NULL) are filled
+ * after the batch completes.  Frames are written at d_out + out_off[i]. */
+int  skyhip_process_device(skyhip_ctx* ctx, int n,
+                           const void* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                           void* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                           uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags);
+
+/* CDC results of the LAST process_* call that had SKYHIP_F_CDC set (host copies).
+ * n_cuts[i] cut END offsets for chunk i are written to cuts + cut_prefix[i] ... ; fps holds 16 bytes per
+ * segment in the same order; first_seen[k] = global index of the first segment with that fingerprint
+ * (== its own global index when it is not a duplicate).  Any pointer may be NULL. */
+int  skyhip_cdc_results(skyhip_ctx* ctx, int n, uint64_t* cut_prefix /* n+1 */, uint32_t* cuts, size_t cuts_cap,
+                        uint8_t* fps, uint64_t* first_seen, uint64_t* seg_base_index);
+
+/* Forget every fingerprint in the dedup table. */
+int  skyhip_dedup_reset(skyhip_ctx* ctx);
+
+void skyhip_get_timing(skyhip_ctx* ctx, skyhip_timing* out);
+void skyhip_reset_timing(skyhip_ctx* ctx);
+
+/* On-device self test of the wavefront primitives (DPP scan vs ds_bpermute scan, ballot, readlane).
+ * Returns 0 when every check passes, otherwise the index (>0) of the first failing check. */
+int  skyhip_selftest(skyhip_ctx* ctx);
+
+const char* skyhip_strerror(int code);
+const char* skyhip_last_hip_error(skyhip_ctx* ctx);   /* hipGetErrorString of the last failing HIP call */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKYHIP_H */

@@ -1,0 +1,469 @@
+// skyhip.hip -- device entry points + host side of the C ABI declared in include/skyhip.h.
+//
+// gfx950 only.  No CPU fallback lives here: if the HIP runtime or the device is missing every call fails
+// with a negative code and the Python binding raises.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "skyhip.h"
+#include "wave.h"
+#include "skyhip_kernels.h"
+#include "lz4_kernel.inc"
+#include "md5_kernel.inc"
+#include "frame_kernel.inc"
+#ifdef SKY_WITH_CDC
+#include "gear_kernel.inc"
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// __global__ wrappers around the portable kernel bodies
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compress(SkyLz4Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4_compress_body(a, smem);
+}
+extern "C" __global__ void __launch_bounds__(64) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
+#ifdef SKY_WITH_CDC
+extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) sky_gear_candidates(SkyGearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_gear_candidates_body(a, smem);
+}
+extern "C" __global__ void __launch_bounds__(64) sky_gear_select(SkyGearArgs a) { sky_gear_select_body(a); }
+extern "C" __global__ void __launch_bounds__(64) sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_dedup_insert(SkyDedupArgs a) { sky_dedup_insert_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_dedup_resolve(SkyDedupArgs a) { sky_dedup_resolve_body(a); }
+#endif
+
+// wave-primitive self test: one wave, results[k] != 0 marks a failing check
+extern "C" __global__ void __launch_bounds__(64) sky_selftest_kernel(const uint8_t* buf, uint8_t* wbuf, uint32_t* results) {
+    const int lane = sky_lane();
+    // 1: DPP scan == ds_bpermute scan on a non-trivial pattern
+    uint32_t x = (uint32_t)(lane * 2654435761u) >> 20;
+    uint32_t a = sky_scan_incl_add(x), b = sky_scan_incl_add_shfl(x);
+    uint32_t ref = 0;
+    for (int i = 0; i <= lane; i++) ref += ((uint32_t)(i * 2654435761u) >> 20);
+    sky_u64 bad1 = sky_ballot(a != b || a != ref);
+    // 2: ballot / ctz / readlane
+    sky_u64 m = sky_ballot((lane % 3) == 1);
+    uint32_t r7 = sky_readlane((uint32_t)lane * 5u + 1u, 7);
+    bool bad2 = (sky_ctz64(m) != 1) || (sky_popc64(m) != 21) || (r7 != 36u);
+    // 3: unaligned loads of every width at odd offsets
+    const uint8_t* p = buf + 1 + lane * 3;
+    uint32_t v32 = sky_ld32u(p);
+    sky_u64 v64 = sky_ld64u(p);
+    sky_u128 v128 = sky_ld128u(p);
+    uint32_t e32 = 0; sky_u64 e64 = 0;
+    for (int k = 0; k < 4; k++) e32 |= (uint32_t)p[k] << (8 * k);
+    for (int k = 0; k < 8; k++) e64 |= (sky_u64)p[k] << (8 * k);
+    uint32_t e3 = 0; for (int k = 0; k < 4; k++) e3 |= (uint32_t)p[12 + k] << (8 * k);
+    sky_u64 bad3 = sky_ballot(v32 != e32 || v64 != e64 || v128.x != e32 || v128.w != e3);
+    // 4: unaligned stores
+    uint8_t* q = wbuf + 1 + lane * 19;
+    sky_st128u(q, v128); sky_st16u(q + 16, 0xBEEFu);
+    __threadfence_block();
+    bool okst = true;
+    for (int k = 0; k < 16; k++) okst &= (q[k] == p[k]);
+    okst &= (q[16] == 0xEF && q[17] == 0xBE);
+    sky_u64 bad4 = sky_ballot(!okst);
+    // 5: shfl
+    uint32_t s = sky_shfl((uint32_t)lane + 100u, (lane * 7 + 3) & 63);
+    sky_u64 bad5 = sky_ballot(s != (uint32_t)((lane * 7 + 3) & 63) + 100u);
+    if (lane == 0) {
+        results[0] = bad1 != 0; results[1] = bad2; results[2] = bad3 != 0; results[3] = bad4 != 0; results[4] = bad5 != 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct EvPair { hipEvent_t a, b; int kind; };
+enum { K_LZ4 = 0, K_LAYOUT, K_GATHER, K_MD5, K_CDC, K_N };
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct skyhip_ctx {
+    int dev = 0;
+    size_t max_chunk = 0;
+    int max_batch = 0;
+    uint32_t blocks_per_chunk = 0;
+    hipStream_t s_lz4 = nullptr, s_md5 = nullptr, s_cdc = nullptr;
+    // per-chunk metadata (whole batch)
+    DevBuf<sky_u64> d_in_off, d_out_off, d_frame_len;
+    DevBuf<uint32_t> d_in_len, d_blk_prefix;
+    DevBuf<uint8_t> d_md5;
+    PinBuf<sky_u64> h_in_off, h_out_off, h_frame_len;
+    PinBuf<uint32_t> h_in_len, h_blk_prefix;
+    PinBuf<uint8_t> h_md5;
+    // per-block data for one sub-batch
+    DevBuf<uint8_t> d_scratch;
+    DevBuf<uint32_t> d_csize, d_blk_word;
+    DevBuf<sky_u64> d_blk_dst;
+    // host-batch staging
+    DevBuf<uint8_t> d_stage_in, d_stage_out;
+#ifdef SKY_WITH_CDC
+    SkyCdcState cdc;   // CDC / dedup state
+#endif
+    // timing
+    std::vector<EvPair> ev_busy, ev_free;
+    skyhip_timing tm;
+    char hip_err[256];
+    uint32_t* d_self = nullptr;
+};
+
+#define HIPCHK(ctx, expr)                                                                             \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            snprintf((ctx)->hip_err, sizeof((ctx)->hip_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP;                         \
+        }                                                                                             \
+    } while (0)
+
+static int ev_begin(skyhip_ctx* c, hipStream_t s, int kind, EvPair* out) {
+    EvPair p;
+    if (!c->ev_free.empty()) { p = c->ev_free.back(); c->ev_free.pop_back(); }
+    else { HIPCHK(c, hipEventCreate(&p.a)); HIPCHK(c, hipEventCreate(&p.b)); }
+    p.kind = kind;
+    HIPCHK(c, hipEventRecord(p.a, s));
+    *out = p;
+    return 0;
+}
+static int ev_end(skyhip_ctx* c, hipStream_t s, EvPair& p) {
+    HIPCHK(c, hipEventRecord(p.b, s));
+    c->ev_busy.push_back(p);
+    return 0;
+}
+static void ev_collect(skyhip_ctx* c) {
+    for (auto& p : c->ev_busy) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            switch (p.kind) {
+                case K_LZ4: c->tm.lz4_ms += ms; break;
+                case K_LAYOUT: c->tm.layout_ms += ms; break;
+                case K_GATHER: c->tm.gather_ms += ms; break;
+                case K_MD5: c->tm.md5_ms += ms; break;
+                case K_CDC: c->tm.cdc_ms += ms; break;
+            }
+        }
+        c->ev_free.push_back(p);
+    }
+    c->ev_busy.clear();
+}
+
+extern "C" {
+
+int skyhip_abi_version(void) { return SKYHIP_ABI_VERSION; }
+
+size_t skyhip_frame_bound(size_t raw_len) {
+    size_t nblk = (raw_len + SKY_LZ4_BLOCK - 1) / SKY_LZ4_BLOCK;
+    return SKY_FRAME_HDR + raw_len + 4 * nblk + 4;
+}
+
+const char* skyhip_strerror(int code) {
+    switch (code) {
+        case SKYHIP_OK: return "ok";
+        case SKYHIP_E_INVAL: return "invalid argument";
+        case SKYHIP_E_NOMEM: return "out of device or pinned host memory";
+        case SKYHIP_E_HIP: return "HIP runtime call or kernel launch failed";
+        case SKYHIP_E_TOOBIG: return "chunk or batch larger than the context was created for";
+        case SKYHIP_E_CAP: return "output buffer smaller than skyhip_frame_bound / cut capacity";
+        case SKYHIP_E_NODEVICE: return "no usable gfx950 device";
+        case SKYHIP_E_TABLEFULL: return "dedup table full";
+        default: return "unknown skyhip error";
+    }
+}
+
+const char* skyhip_last_hip_error(skyhip_ctx* ctx) { return ctx ? ctx->hip_err : ""; }
+
+int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_ctx** out) {
+    if (!out || max_batch <= 0 || max_chunk_bytes == 0 || max_chunk_bytes > ((size_t)1 << 30)) return SKYHIP_E_INVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SKYHIP_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return SKYHIP_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SKYHIP_E_NODEVICE;   // this library carries gfx950 code only
+    skyhip_ctx* c = new (std::nothrow) skyhip_ctx();
+    if (!c) return SKYHIP_E_NOMEM;
+    c->hip_err[0] = 0;
+    memset(&c->tm, 0, sizeof c->tm);
+    c->dev = device_id; c->max_chunk = max_chunk_bytes; c->max_batch = max_batch;
+    c->blocks_per_chunk = (uint32_t)((max_chunk_bytes + SKY_LZ4_BLOCK - 1) / SKY_LZ4_BLOCK);
+    int rc = [&]() -> int {
+        HIPCHK(c, hipSetDevice(device_id));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_lz4, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_md5, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_cdc, hipStreamNonBlocking));
+        const size_t nb = (size_t)max_batch * c->blocks_per_chunk;
+        HIPCHK(c, c->d_scratch.ensure(nb * SKY_LZ4_SLOT));
+        HIPCHK(c, c->d_csize.ensure(nb));
+        HIPCHK(c, c->d_blk_word.ensure(nb));
+        HIPCHK(c, c->d_blk_dst.ensure(nb));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_compress, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4_LDS_BYTES));
+        return 0;
+    }();
+    if (rc) { skyhip_destroy(c); return rc; }
+    *out = c;
+    return SKYHIP_OK;
+}
+
+void skyhip_destroy(skyhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    if (c->s_lz4) (void)hipStreamSynchronize(c->s_lz4);
+    if (c->s_md5) (void)hipStreamSynchronize(c->s_md5);
+    if (c->s_cdc) (void)hipStreamSynchronize(c->s_cdc);
+    ev_collect(c);
+    for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
+    c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
+    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release();
+    c->d_stage_in.release(); c->d_stage_out.release();
+#ifdef SKY_WITH_CDC
+    sky_cdc_state_release(&c->cdc);
+#endif
+    if (c->d_self) (void)hipFree(c->d_self);
+    if (c->s_lz4) (void)hipStreamDestroy(c->s_lz4);
+    if (c->s_md5) (void)hipStreamDestroy(c->s_md5);
+    if (c->s_cdc) (void)hipStreamDestroy(c->s_cdc);
+    delete c;
+}
+
+void skyhip_get_timing(skyhip_ctx* c, skyhip_timing* out) { if (c && out) *out = c->tm; }
+void skyhip_reset_timing(skyhip_ctx* c) { if (c) memset(&c->tm, 0, sizeof c->tm); }
+
+int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
+                          const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !in_off || !in_len))) return SKYHIP_E_INVAL;
+    if ((flags & SKYHIP_F_LZ4) && n > 0 && (!d_out || !out_off || !out_cap)) return SKYHIP_E_INVAL;
+    if ((flags & SKYHIP_F_DEDUP) && !(flags & SKYHIP_F_CDC)) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const size_t N = (size_t)n;
+    HIPCHK(c, c->h_in_off.ensure(N)); HIPCHK(c, c->h_out_off.ensure(N)); HIPCHK(c, c->h_frame_len.ensure(N));
+    HIPCHK(c, c->h_in_len.ensure(N)); HIPCHK(c, c->h_blk_prefix.ensure(N + 1)); HIPCHK(c, c->h_md5.ensure(16 * N));
+    HIPCHK(c, c->d_in_off.ensure(N)); HIPCHK(c, c->d_out_off.ensure(N)); HIPCHK(c, c->d_frame_len.ensure(N));
+    HIPCHK(c, c->d_in_len.ensure(N)); HIPCHK(c, c->d_blk_prefix.ensure(N + 1)); HIPCHK(c, c->d_md5.ensure(16 * N));
+    uint64_t nblk_total = 0, bytes_total = 0;
+    for (size_t i = 0; i < N; i++) {
+        if (in_len[i] > c->max_chunk) return SKYHIP_E_TOOBIG;
+        if ((flags & SKYHIP_F_LZ4) && out_cap[i] < skyhip_frame_bound((size_t)in_len[i])) return SKYHIP_E_CAP;
+        c->h_in_off.p[i] = in_off[i];
+        c->h_in_len.p[i] = (uint32_t)in_len[i];
+        c->h_out_off.p[i] = (flags & SKYHIP_F_LZ4) ? out_off[i] : 0;
+        c->h_blk_prefix.p[i] = (uint32_t)nblk_total;
+        nblk_total += (in_len[i] + SKY_LZ4_BLOCK - 1) / SKY_LZ4_BLOCK;
+        bytes_total += in_len[i];
+        if (nblk_total > 0xFFFFFFF0ull) return SKYHIP_E_TOOBIG;
+    }
+    c->h_blk_prefix.p[N] = (uint32_t)nblk_total;
+    // metadata upload on the lz4 stream; the other streams wait on an event
+    HIPCHK(c, hipMemcpyAsync(c->d_in_off.p, c->h_in_off.p, N * 8, hipMemcpyHostToDevice, c->s_lz4));
+    HIPCHK(c, hipMemcpyAsync(c->d_in_len.p, c->h_in_len.p, N * 4, hipMemcpyHostToDevice, c->s_lz4));
+    HIPCHK(c, hipMemcpyAsync(c->d_out_off.p, c->h_out_off.p, N * 8, hipMemcpyHostToDevice, c->s_lz4));
+    HIPCHK(c, hipMemcpyAsync(c->d_blk_prefix.p, c->h_blk_prefix.p, (N + 1) * 4, hipMemcpyHostToDevice, c->s_lz4));
+    hipEvent_t meta_ready;
+    HIPCHK(c, hipEventCreateWithFlags(&meta_ready, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(meta_ready, c->s_lz4));
+
+    int rc = 0;
+    // ---- MD5 first: few, long-running waves; they become resident and the LZ4 grid fills the rest ----
+    if (flags & SKYHIP_F_MD5) {
+        HIPCHK(c, hipStreamWaitEvent(c->s_md5, meta_ready, 0));
+        SkyMd5Args ma;
+        ma.in = (const uint8_t*)d_in; ma.off = c->d_in_off.p; ma.len = c->d_in_len.p; ma.n = (uint32_t)N; ma.digest = c->d_md5.p;
+        EvPair ep;
+        if ((rc = ev_begin(c, c->s_md5, K_MD5, &ep))) return rc;
+        hipLaunchKernelGGL(sky_md5_chunks, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->s_md5, ma);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = ev_end(c, c->s_md5, ep))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_md5.p, c->d_md5.p, 16 * N, hipMemcpyDeviceToHost, c->s_md5));
+        c->tm.md5_launches++; c->tm.md5_in_bytes += bytes_total;
+    }
+    // ---- CDC (+ fingerprints, dedup) on its own stream ----
+    if (flags & SKYHIP_F_CDC) {
+#ifndef SKY_WITH_CDC
+        return SKYHIP_E_INVAL;
+#else
+        HIPCHK(c, hipStreamWaitEvent(c->s_cdc, meta_ready, 0));
+        EvPair ep;
+        if ((rc = ev_begin(c, c->s_cdc, K_CDC, &ep))) return rc;
+        rc = sky_cdc_run(&c->cdc, c->s_cdc, (const uint8_t*)d_in, c->d_in_off.p, c->d_in_len.p, c->h_in_len.p, (uint32_t)N,
+                         (flags & SKYHIP_F_DEDUP) != 0, c->hip_err, sizeof c->hip_err);
+        if (rc) return rc;
+        if ((rc = ev_end(c, c->s_cdc, ep))) return rc;
+#endif
+    }
+    // ---- LZ4: sub-batches of max_batch chunks share the block scratch ----
+    if (flags & SKYHIP_F_LZ4) {
+        for (size_t c0 = 0; c0 < N; c0 += (size_t)c->max_batch) {
+            const size_t nc = (N - c0 < (size_t)c->max_batch) ? N - c0 : (size_t)c->max_batch;
+            const uint32_t nb = c->h_blk_prefix.p[c0 + nc] - c->h_blk_prefix.p[c0];
+            uint64_t sub_bytes = 0;
+            for (size_t i = c0; i < c0 + nc; i++) sub_bytes += c->h_in_len.p[i];
+            SkyLz4Args la;
+            la.in = (const uint8_t*)d_in; la.in_off = c->d_in_off.p + c0; la.in_len = c->d_in_len.p + c0; la.blk_prefix = c->d_blk_prefix.p + c0;
+            la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch.p; la.csize = c->d_csize.p;
+            SkyFrameArgs fa;
+            fa.in = la.in; fa.in_off = la.in_off; fa.in_len = la.in_len; fa.blk_prefix = la.blk_prefix; fa.n_chunks = la.n_chunks; fa.n_blocks = nb;
+            fa.scratch = c->d_scratch.p; fa.csize = c->d_csize.p; fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p + c0;
+            fa.frame_len = c->d_frame_len.p + c0; fa.blk_dst = c->d_blk_dst.p; fa.blk_word = c->d_blk_word.p;
+            EvPair ep;
+            if (nb) {
+                if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
+                hipLaunchKernelGGL(sky_lz4_compress, dim3((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES), dim3(SKY_LZ4_WAVES * 64), SKY_LZ4_LDS_BYTES, c->s_lz4, la);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+                c->tm.lz4_launches++; c->tm.lz4_in_bytes += sub_bytes;
+            }
+            if ((rc = ev_begin(c, c->s_lz4, K_LAYOUT, &ep))) return rc;
+            hipLaunchKernelGGL(sky_frame_layout, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, c->s_lz4, fa);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+            if (nb) {
+                if ((rc = ev_begin(c, c->s_lz4, K_GATHER, &ep))) return rc;
+                hipLaunchKernelGGL(sky_frame_gather, dim3(nb), dim3(256), 0, c->s_lz4, fa);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_lz4));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    HIPCHK(c, hipStreamSynchronize(c->s_md5));
+    HIPCHK(c, hipStreamSynchronize(c->s_cdc));
+    (void)hipEventDestroy(meta_ready);
+    ev_collect(c);
+    if (flags & SKYHIP_F_LZ4) {
+        for (size_t i = 0; i < N; i++) {
+            c->tm.lz4_out_bytes += c->h_frame_len.p[i];
+            if (out_len) out_len[i] = c->h_frame_len.p[i];
+        }
+    }
+    if ((flags & SKYHIP_F_MD5) && md5) memcpy(md5, c->h_md5.p, 16 * N);
+    return SKYHIP_OK;
+}
+
+int skyhip_process_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
+                         size_t* out_len, uint8_t (*md5)[16], uint32_t* const* cuts, const size_t* cuts_cap, size_t* n_cuts, uint32_t flags) {
+    if (!c || n < 0) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    if (!in || !in_len) return SKYHIP_E_INVAL;
+    if ((flags & SKYHIP_F_LZ4) && (!out || !out_cap || !out_len)) return SKYHIP_E_INVAL;
+    if ((flags & SKYHIP_F_MD5) && !md5) return SKYHIP_E_INVAL;
+    if ((flags & SKYHIP_F_CDC) && (!cuts || !cuts_cap || !n_cuts)) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const size_t in_stride = (c->max_chunk + 255) & ~(size_t)255;
+    const size_t out_stride = (skyhip_frame_bound(c->max_chunk) + 255) & ~(size_t)255;
+    HIPCHK(c, c->d_stage_in.ensure(in_stride * (size_t)c->max_batch));
+    if (flags & SKYHIP_F_LZ4) HIPCHK(c, c->d_stage_out.ensure(out_stride * (size_t)c->max_batch));
+    std::vector<uint64_t> off_in(c->max_batch), len_in(c->max_batch), off_out(c->max_batch), cap_out(c->max_batch), flen(c->max_batch);
+    for (int c0 = 0; c0 < n; c0 += c->max_batch) {
+        const int nc = (n - c0 < c->max_batch) ? n - c0 : c->max_batch;
+        for (int i = 0; i < nc; i++) {
+            const size_t L = in_len[c0 + i];
+            if (L > c->max_chunk) return SKYHIP_E_TOOBIG;
+            if (L && !in[c0 + i]) return SKYHIP_E_INVAL;
+            if ((flags & SKYHIP_F_LZ4) && out_cap[c0 + i] < skyhip_frame_bound(L)) return SKYHIP_E_CAP;
+            off_in[i] = in_stride * (size_t)i; len_in[i] = L; off_out[i] = out_stride * (size_t)i; cap_out[i] = out_stride;
+            if (L) HIPCHK(c, hipMemcpyAsync(c->d_stage_in.p + off_in[i], in[c0 + i], L, hipMemcpyHostToDevice, c->s_lz4));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+        int rc = skyhip_process_device(c, nc, c->d_stage_in.p, off_in.data(), len_in.data(), c->d_stage_out.p, off_out.data(), cap_out.data(),
+                                       flen.data(), md5 ? md5 + c0 : nullptr, flags);
+        if (rc) return rc;
+        if (flags & SKYHIP_F_LZ4) {
+            for (int i = 0; i < nc; i++) {
+                out_len[c0 + i] = (size_t)flen[i];
+                HIPCHK(c, hipMemcpyAsync(out[c0 + i], c->d_stage_out.p + off_out[i], flen[i], hipMemcpyDeviceToHost, c->s_lz4));
+            }
+            HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+        }
+#ifdef SKY_WITH_CDC
+        if (flags & SKYHIP_F_CDC) {
+            rc = sky_cdc_copy_cuts(&c->cdc, nc, cuts + c0, cuts_cap + c0, n_cuts + c0);
+            if (rc) return rc;
+        }
+#endif
+    }
+    return SKYHIP_OK;
+}
+
+int skyhip_cdc_results(skyhip_ctx* c, int n, uint64_t* cut_prefix, uint32_t* cuts, size_t cuts_cap, uint8_t* fps, uint64_t* first_seen,
+                       uint64_t* seg_base_index) {
+    if (!c) return SKYHIP_E_INVAL;
+#ifdef SKY_WITH_CDC
+    return sky_cdc_results(&c->cdc, n, cut_prefix, cuts, cuts_cap, fps, first_seen, seg_base_index);
+#else
+    (void)n; (void)cut_prefix; (void)cuts; (void)cuts_cap; (void)fps; (void)first_seen; (void)seg_base_index;
+    return SKYHIP_E_INVAL;
+#endif
+}
+
+int skyhip_dedup_reset(skyhip_ctx* c) {
+    if (!c) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+#ifdef SKY_WITH_CDC
+    return sky_dedup_reset(&c->cdc, c->s_cdc);
+#else
+    return SKYHIP_E_INVAL;
+#endif
+}
+
+int skyhip_selftest(skyhip_ctx* c) {
+    if (!c) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    uint8_t* d_buf = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_buf, 8192));
+    uint8_t h[4096];
+    for (int i = 0; i < 4096; i++) h[i] = (uint8_t)(i * 37 + (i >> 3));
+    HIPCHK(c, hipMemcpy(d_buf, h, 4096, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(d_buf + 4096, 0, 4096));
+    uint32_t* d_res = (uint32_t*)(d_buf + 4096 + 2048);
+    hipLaunchKernelGGL(sky_selftest_kernel, dim3(1), dim3(64), 0, c->s_lz4, d_buf, d_buf + 4096, d_res);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    uint32_t res[8] = {0};
+    HIPCHK(c, hipMemcpy(res, d_res, sizeof(uint32_t) * 5, hipMemcpyDeviceToHost));
+    (void)hipFree(d_buf);
+    for (int k = 0; k < 5; k++) if (res[k]) return k + 1;
+    return 0;
+}
+
+}  // extern "C"

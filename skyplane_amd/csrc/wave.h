@@ -1,0 +1,94 @@
+// wave.h -- the small set of wavefront primitives the skyhip kernels are written against.
+//
+// Device build (hipcc, gfx950): each primitive is a CDNA4 builtin -- 64-wide ballots, readlane,
+// ds_bpermute shuffles and DPP row-shift scans.  There is no 32-wide path and no CUDA spelling.
+//
+// SKY_EMU build (g++, tests/emu only): the same names are provided by tests/emu/emu.h, a fiber-based
+// SIMT emulator that runs every lane of a workgroup as a coroutine and resolves each collective when
+// all live lanes of the wave have arrived.  That lets the CPU test-suite execute the *shipping kernel
+// source* on a box with no GPU.  The emulator is test infrastructure: nothing in the product links it.
+//
+// Contract for kernel authors: every collective (ballot / readlane / shfl / scan / barrier) is called
+// in wave-uniform control flow.
+#pragma once
+#include <stdint.h>
+
+#ifdef SKY_EMU
+#include "emu.h"
+#else
+#include <hip/hip_runtime.h>
+
+#define SKY_DEV __device__ __forceinline__
+#define SKY_WAVE 64
+
+typedef unsigned long long sky_u64;
+
+SKY_DEV int sky_tid() { return (int)threadIdx.x; }
+SKY_DEV int sky_bid() { return (int)blockIdx.x; }
+SKY_DEV int sky_bdim() { return (int)blockDim.x; }
+SKY_DEV int sky_gdim() { return (int)gridDim.x; }
+SKY_DEV int sky_lane() { return (int)(threadIdx.x & 63u); }
+SKY_DEV int sky_wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+SKY_DEV sky_u64 sky_ballot(bool p) { return __ballot(p); }
+SKY_DEV uint32_t sky_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// arbitrary gather across lanes (ds_bpermute_b32)
+SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+SKY_DEV void sky_syncthreads() { __syncthreads(); }
+// compile-time ordering of this wave's LDS/global accesses (lanes of one wave execute DS ops in issue order)
+SKY_DEV void sky_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+#ifndef SKY_SCAN_SHFL
+// DPP inclusive add-scan over the 64 lanes: 4 row_shr steps inside each 16-lane row, then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 (gfx9-family DPP controls).
+SKY_DEV uint32_t sky_scan_incl_add(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
+}
+#else
+// reference form of the same scan through ds_bpermute (kept for the on-GPU self-test)
+SKY_DEV uint32_t sky_scan_incl_add(uint32_t x) {
+    const int lane = sky_lane();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = sky_shfl(x, (lane - d) & 63);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+#endif
+SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t x) {
+    const int lane = sky_lane();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = sky_shfl(x, (lane - d) & 63);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+
+SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { return atomicMin(p, v); }
+SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 expect, sky_u64 desired) { return atomicCAS(p, expect, desired); }
+SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
+SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+#endif  // SKY_EMU
+
+// ---- helpers common to both builds ---------------------------------------------------------------
+// Unaligned little-endian loads.  gfx950 under amdhsa runs with unaligned access mode enabled, so the
+// compiler turns these memcpys into single global_load_dword / dwordx2 / dwordx4 instructions.
+SKY_DEV uint32_t sky_ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+SKY_DEV sky_u64 sky_ld64u(const uint8_t* p) { sky_u64 v; __builtin_memcpy(&v, p, 8); return v; }
+SKY_DEV void sky_st16u(uint8_t* p, uint32_t v) { uint16_t s = (uint16_t)v; __builtin_memcpy(p, &s, 2); }
+SKY_DEV void sky_st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+struct sky_u128 { uint32_t x, y, z, w; };
+SKY_DEV sky_u128 sky_ld128u(const uint8_t* p) { sky_u128 v; __builtin_memcpy(&v, p, 16); return v; }
+SKY_DEV void sky_st128u(uint8_t* p, const sky_u128& v) { __builtin_memcpy(p, &v, 16); }

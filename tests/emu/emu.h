@@ -1,0 +1,67 @@
+// emu.h -- fiber-based SIMT emulator: TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Runs the shipping kernel source (skyplane_amd/csrc/*.inc, written against wave.h) on the CPU:
+// every lane of a workgroup is a coroutine with its own stack; a collective parks the lane until all
+// live lanes of its wave (or workgroup, for the barrier) have arrived, then the scheduler resolves it.
+// Semantics mirrored from gfx950: 64-lane waves, ballot over live lanes only, ds_bpermute reads 0 from
+// exited lanes.  Collectives must be called in wave-uniform control flow (asserted).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#define SKY_DEV static inline
+#define SKY_WAVE 64
+typedef unsigned long long sky_u64;
+
+enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT };
+
+struct EmuLaneState {
+    void* sp;            // saved stack pointer of the parked coroutine
+    void* stack;
+    int tid;
+    int op;              // collective the lane is parked at
+    sky_u64 arg0;        // value
+    sky_u64 arg1;        // lane index / predicate
+    sky_u64 result;
+    bool done;
+};
+
+struct EmuBlockCtx {
+    int bid, bdim, gdim;
+    EmuLaneState* lanes;
+    void* sched_sp;
+};
+
+extern thread_local EmuBlockCtx* emu_blk;
+extern thread_local EmuLaneState* emu_cur;
+sky_u64 emu_collective(int op, sky_u64 a0, sky_u64 a1);
+
+SKY_DEV int sky_tid() { return emu_cur->tid; }
+SKY_DEV int sky_bid() { return emu_blk->bid; }
+SKY_DEV int sky_bdim() { return emu_blk->bdim; }
+SKY_DEV int sky_gdim() { return emu_blk->gdim; }
+SKY_DEV int sky_lane() { return emu_cur->tid & 63; }
+SKY_DEV int sky_wave_in_block() { return emu_cur->tid >> 6; }
+
+SKY_DEV sky_u64 sky_ballot(bool p) { return emu_collective(EMU_BALLOT, p ? 1 : 0, 0); }
+SKY_DEV uint32_t sky_readlane(uint32_t v, int lane) { return (uint32_t)emu_collective(EMU_READLANE, v, (sky_u64)lane); }
+SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, v, (sky_u64)-1); }
+SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective(EMU_SHFL, v, (sky_u64)(src & 63)); }
+SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
+SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
+SKY_DEV void sky_syncthreads() { emu_collective(EMU_BARRIER, 0, 0); }
+SKY_DEV void sky_wave_fence() {}
+
+// lanes never run concurrently, so plain read-modify-write is atomic here
+SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { sky_u64 o = *p; if (v < o) *p = v; return o; }
+SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 e, sky_u64 d) { sky_u64 o = *p; if (o == e) *p = d; return o; }
+SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
+
+SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
+SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+
+// Launch: run `body(args)` for every thread of every workgroup, one workgroup at a time.
+// `smem` is the workgroup's LDS (zero-filled is NOT guaranteed on hardware; the emulator poisons it).
+typedef void (*EmuKernelBody)(void* args, uint8_t* smem);
+void emu_launch(int grid, int block, size_t lds_bytes, EmuKernelBody body, void* args);

@@ -1,0 +1,66 @@
+"""ctypes face of tests/emu/_build/libskyemu.so: the shipping kernel source run under the CPU SIMT
+emulator.  TEST INFRASTRUCTURE ONLY -- lets `-m "not gpu"` tests execute the kernels' logic without a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libskyemu.so"
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-s", "-C", str(_HERE)], check=True)
+        l = C.CDLL(str(_SO))
+        l.emu_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        l.emu_process.restype = C.c_int
+        l.emu_lz4_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        l.emu_lz4_block.restype = C.c_uint32
+        l.emu_slot_bytes.restype = C.c_uint32
+        _lib = l
+    return _lib
+
+
+def frame_bound(n: int) -> int:
+    return 15 + n + 4 * ((n + 65535) // 65536) + 4
+
+
+def process(chunks, flags=3, blk_skew=0):
+    """chunks: list of bytes. Returns (frames: list[bytes], md5s: list[bytes], csizes)."""
+    n = len(chunks)
+    lens = np.array([len(c) for c in chunks], np.uint64)
+    in_off = np.zeros(n, np.uint64)
+    pos = 0
+    for i, c in enumerate(chunks):
+        in_off[i] = pos
+        pos += (len(c) + 63) & ~63
+    buf = np.zeros(max(pos, 64) + 64, np.uint8)
+    for i, c in enumerate(chunks):
+        buf[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+    out_off = np.zeros(n, np.uint64)
+    pos = 3  # deliberately misaligned frame starts
+    for i, c in enumerate(chunks):
+        out_off[i] = pos
+        pos += frame_bound(len(c)) + 5
+    out = np.full(pos + 64, 0xEE, np.uint8)
+    flen = np.zeros(n, np.uint64)
+    md5 = np.zeros((n, 16), np.uint8)
+    nb = int(sum((len(c) + 65535) // 65536 for c in chunks))
+    cs = np.zeros(max(nb, 1), np.uint32)
+    rc = lib().emu_process(buf.ctypes.data, in_off.ctypes.data, lens.ctypes.data, n, out.ctypes.data, out_off.ctypes.data, flen.ctypes.data,
+                           md5.ctypes.data, flags, blk_skew, cs.ctypes.data)
+    assert rc == 0
+    frames = [out[int(out_off[i]):int(out_off[i]) + int(flen[i])].tobytes() for i in range(n)]
+    # guard bytes between frames must be untouched
+    for i in range(n):
+        end = int(out_off[i]) + int(flen[i])
+        nxt = int(out_off[i + 1]) if i + 1 < n else out.size
+        if flags & 1:
+            assert (out[end:nxt] == 0xEE).all(), f"frame {i} wrote past its length"
+    return frames, [md5[i].tobytes() for i in range(n)], cs[:nb]
