@@ -1,0 +1,143 @@
+"""Thin Python face of libskyhip.so -- the `skyplane/gateway/hip_ops` extension named by BASELINE.json.
+
+Replaces, for one batch of chunks, the two CPU calls of the reference's source-gateway hot path:
+  * ``lz4.frame.compress(data)``           skyplane/gateway/operators/gateway_operator.py:358-361
+  * ``hashlib.md5(...).digest()``           skyplane/obj_store/s3_interface.py:181-192 (requested at gateway_operator.py:555-565)
+and adds Gear CDC cut points / segment fingerprints / dedup lookups (new; not in the reference).
+
+Everything here is plumbing over the C ABI in include/skyhip.h; all arithmetic runs in HIP kernels on gfx950.
+There is no CPU fallback: construction raises if the extension or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import SkyHipError, Timing
+
+F_LZ4, F_MD5, F_CDC, F_DEDUP = 1, 2, 4, 8
+
+
+def frame_bound(raw_len: int) -> int:
+    return int(_lib.load().skyhip_frame_bound(raw_len))
+
+
+@dataclass
+class ChunkResult:
+    frame: Optional[bytes]   # LZ4 frame (what GatewaySender puts on the wire when is_compressed=True)
+    md5: Optional[bytes]     # 16-byte digest == hashlib.md5(raw).digest()
+    cuts: Optional[np.ndarray] = None  # CDC END offsets (uint32), last == len(raw)
+
+
+class SkyHipContext:
+    """One per worker process, created AFTER fork (HIP must never be initialised in the daemon parent)."""
+
+    def __init__(self, device_id: int = 0, max_chunk_bytes: int = 64 << 20, max_batch: int = 8):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.skyhip_create(device_id, max_chunk_bytes, max_batch, C.byref(h))
+        if rc != 0:
+            raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode())
+        self._h = h
+        self.device_id, self.max_chunk_bytes, self.max_batch = device_id, max_chunk_bytes, max_batch
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.skyhip_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            detail = self._lib.skyhip_last_hip_error(self._h).decode()
+            raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode() + (f" [{detail}]" if detail else ""))
+
+    # -- host-buffer path (what the gateway operator uses) -------------------------------------------
+    def process_batch(self, chunks: Sequence, flags: int = F_LZ4 | F_MD5) -> List[ChunkResult]:
+        n = len(chunks)
+        if n == 0:
+            return []
+        arrs = [np.frombuffer(c, np.uint8) if not isinstance(c, np.ndarray) else np.ascontiguousarray(c.reshape(-1).view(np.uint8)) for c in chunks]
+        in_ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        in_len = (C.c_size_t * n)(*[a.size for a in arrs])
+        outs, out_ptrs, out_cap, out_len = [], None, None, None
+        if flags & F_LZ4:
+            outs = [np.empty(frame_bound(a.size), np.uint8) for a in arrs]
+            out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+            out_cap = (C.c_size_t * n)(*[o.size for o in outs])
+            out_len = (C.c_size_t * n)()
+        md5 = np.zeros((n, 16), np.uint8) if flags & F_MD5 else None
+        cuts, cut_ptrs, cut_cap, n_cuts = [], None, None, None
+        if flags & F_CDC:
+            cuts = [np.empty(a.size // 4096 + 2, np.uint32) for a in arrs]
+            cut_ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in cuts])
+            cut_cap = (C.c_size_t * n)(*[c.size for c in cuts])
+            n_cuts = (C.c_size_t * n)()
+        rc = self._lib.skyhip_process_batch(self._h, n, in_ptrs, in_len, out_ptrs, out_cap, out_len, md5.ctypes.data if md5 is not None else None,
+                                            cut_ptrs, cut_cap, n_cuts, flags)
+        self._check(rc)
+        res = []
+        for i in range(n):
+            res.append(ChunkResult(frame=outs[i][: out_len[i]].tobytes() if flags & F_LZ4 else None,
+                                   md5=md5[i].tobytes() if md5 is not None else None,
+                                   cuts=cuts[i][: n_cuts[i]].copy() if flags & F_CDC else None))
+        return res
+
+    # -- device-resident path (bench / kernel-only measurements; pointers are raw device addresses) ----
+    def process_device(self, d_in: int, in_off: np.ndarray, in_len: np.ndarray, d_out: int, out_off: np.ndarray, out_cap: np.ndarray,
+                       flags: int = F_LZ4 | F_MD5, want_md5: bool = True):
+        n = int(in_off.size)
+        in_off = np.ascontiguousarray(in_off, np.uint64)
+        in_len = np.ascontiguousarray(in_len, np.uint64)
+        out_off = np.ascontiguousarray(out_off, np.uint64)
+        out_cap = np.ascontiguousarray(out_cap, np.uint64)
+        out_len = np.zeros(n, np.uint64)
+        md5 = np.zeros((n, 16), np.uint8) if (flags & F_MD5 and want_md5) else None
+        rc = self._lib.skyhip_process_device(self._h, n, C.c_void_p(d_in), in_off.ctypes.data, in_len.ctypes.data, C.c_void_p(d_out),
+                                             out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+                                             md5.ctypes.data if md5 is not None else None, flags)
+        self._check(rc)
+        return out_len, md5
+
+    def cdc_results(self, n: int, in_len: np.ndarray):
+        """CDC output of the last call with F_CDC: (cut_prefix[n+1], cuts, fingerprints[nseg,16], first_seen[nseg], seg_base)."""
+        cap = int(sum(int(l) // 4096 + 2 for l in in_len))
+        prefix = np.zeros(n + 1, np.uint64)
+        cuts = np.zeros(max(cap, 1), np.uint32)
+        fps = np.zeros((max(cap, 1), 16), np.uint8)
+        first = np.zeros(max(cap, 1), np.uint64)
+        base = np.zeros(1, np.uint64)
+        rc = self._lib.skyhip_cdc_results(self._h, n, prefix.ctypes.data, cuts.ctypes.data, cap, fps.ctypes.data, first.ctypes.data, base.ctypes.data)
+        self._check(rc)
+        nseg = int(prefix[n])
+        return prefix, cuts[:nseg], fps[:nseg], first[:nseg], int(base[0])
+
+    def dedup_reset(self):
+        self._check(self._lib.skyhip_dedup_reset(self._h))
+
+    def selftest(self) -> int:
+        return int(self._lib.skyhip_selftest(self._h))
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._lib.skyhip_get_timing(self._h, C.byref(t))
+        return t
+
+    def reset_timing(self):
+        self._lib.skyhip_reset_timing(self._h)
