@@ -13,6 +13,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench"
 timeout 900 python bench.py --steps ${STEPS:-3} --warmup 1 --chunks $CHUNKS 2>&1 | tail -5 | tee gpurun_out/bench.log
 echo "== rocprofv3 kernel trace"
-( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -o r1 -- python /root/repo/bench.py --steps 2 --warmup 1 --chunks 512 --no-cpu-baseline > /root/repo/gpurun_out/prof_bench.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof -o r1 -- python /root/repo/bench.py --steps 2 --warmup 1 --chunks 512 --no-cpu-baseline > /root/repo/gpurun_out/prof_bench.log 2>&1 )
 tail -2 gpurun_out/prof_bench.log
-find gpurun_out/prof -name '*stats*' | head; for f in $(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); do head -12 $f; done
+find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do head -12 $f; done
