@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Timing experiment (not a test, not a bench line): LZ4 kernel time with parts switched off via SKYHIP_ABLATE."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from skyplane_amd import hip_ops, synth
+n = int(os.environ.get("CHUNKS", "512")); cb = synth.CHUNK_BYTES
+unit = synth.silesia_like(64 << 20, config_id=2)
+d_unit = torch.from_numpy(unit).cuda()
+d_in = torch.empty(n * cb, dtype=torch.uint8, device="cuda")
+for t in range(n * cb // unit.size):
+    d_in[t * unit.size:(t + 1) * unit.size] = torch.roll(d_unit, -((t * 7919 * 4096 + t * 13) % unit.size))
+stride = (hip_ops.frame_bound(cb) + 255) & ~255
+d_out = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+in_off = np.arange(n, dtype=np.uint64) * cb; in_len = np.full(n, cb, np.uint64)
+out_off = np.arange(n, dtype=np.uint64) * stride; out_cap = np.full(n, stride, np.uint64)
+ctx = hip_ops.SkyHipContext(0, cb, 512)
+for abl in [int(x) for x in os.environ.get("ABLS", "0,1,2,4,5,7,15").split(",")]:
+    os.environ["SKYHIP_ABLATE"] = str(abl)
+    ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
+    ctx.reset_timing()
+    for _ in range(2):
+        ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
+    t = ctx.timing()
+    print(f"ablate={abl:2d} lz4 {t.lz4_ms/2:8.2f} ms  -> {n*cb/ (t.lz4_ms/2e3)/1e9:7.1f} GB/s   gather {t.gather_ms/2:6.2f} ms", flush=True)

@@ -340,6 +340,7 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
             SkyLz4Args la;
             la.in = (const uint8_t*)d_in; la.in_off = c->d_in_off.p + c0; la.in_len = c->d_in_len.p + c0; la.blk_prefix = c->d_blk_prefix.p + c0;
             la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch.p; la.csize = c->d_csize.p;
+            { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing experiments only
             SkyFrameArgs fa;
             fa.in = la.in; fa.in_off = la.in_off; fa.in_len = la.in_len; fa.blk_prefix = la.blk_prefix; fa.n_chunks = la.n_chunks; fa.n_blocks = nb;
             fa.scratch = c->d_scratch.p; fa.csize = c->d_csize.p; fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p + c0;
