@@ -79,12 +79,19 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+// tell the compiler a value is wave-uniform (keeps it in SGPRs; folds away when it already is)
+SKY_DEV uint32_t sky_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // bit `lane` of a wave-uniform mask as a per-lane predicate: the SGPR pair IS the predicate (no shifts)
 SKY_DEV bool sky_lanebit(sky_u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 #endif  // SKY_EMU
 
 // index of the lowest set bit, 0xFFFFFFFF for x == 0 (v_ffbl_b32 semantics on both builds)
+#ifdef SKY_EMU
 SKY_DEV uint32_t sky_ffbl32(uint32_t x) { return (uint32_t)(__builtin_ffs((int)x) - 1); }
+#else
+// one instruction: the hardware already returns -1 for zero, which C's ctz/ffs cannot express without a select
+SKY_DEV uint32_t sky_ffbl32(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#endif
 // index of the highest set bit, 0xFFFFFFFF for x == 0
 SKY_DEV uint32_t sky_flbit32(uint32_t x) { return x ? 31u - (uint32_t)__builtin_clz(x) : 0xFFFFFFFFu; }
 
