@@ -112,6 +112,9 @@ void skyhip_reset_timing(skyhip_ctx* ctx);
  * Returns 0 when every check passes, otherwise the index (>0) of the first failing check. */
 int  skyhip_selftest(skyhip_ctx* ctx);
 
+/* Development aid: accumulated in-kernel phase timers of a -DSKY_PROF=1 build (all zeros in the shipping build). */
+int  skyhip_debug_prof(skyhip_ctx* ctx, uint64_t out[16]);
+
 const char* skyhip_strerror(int code);
 const char* skyhip_last_hip_error(skyhip_ctx* ctx);   /* hipGetErrorString of the last failing HIP call */
 

@@ -22,4 +22,14 @@ for abl in [int(x) for x in os.environ.get("ABLS", "0,1,2,4,5,7,15").split(",")]
     for _ in range(2):
         ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
     t = ctx.timing()
+    import ctypes
+    pr = (ctypes.c_uint64 * 16)()
+    ctx._lib.skyhip_debug_prof(ctx._h, pr)
+    if pr[9]:
+        names = ["A1 input loads", "A2-3 hash/probe/period", "A4 cmp16", "A5 cmp16 #2 + finalize", "B1 parse+install", "B2 tokens", "B2 literals", "B2 carry copy", "block total", "blocks"]
+        tot = pr[8]
+        print("  phase cycles per block (sum over batches) / share of block time:")
+        for i in range(8):
+            print(f"    {names[i]:28s} {pr[i]/pr[9]:12.0f}  {100.0*pr[i]/tot:5.1f}%")
+        print(f"    {'block total':28s} {pr[8]/pr[9]:12.0f}   ({pr[9]} blocks; unattributed {100.0*(tot-sum(pr[:8]))/tot:.1f}%)")
     print(f"ablate={abl:2d} lz4 {t.lz4_ms/2:8.2f} ms  -> {n*cb/ (t.lz4_ms/2e3)/1e9:7.1f} GB/s   gather {t.gather_ms/2:6.2f} ms", flush=True)

@@ -7,12 +7,12 @@ import os
 from pathlib import Path
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libskyhip.so"
+LIB_PATH = Path(os.environ.get("SKYHIP_LIB_PATH", _CSRC / "libskyhip.so"))   # override only for dev builds (profiling)
 
 EXPORTS = (
     "skyhip_abi_version", "skyhip_create", "skyhip_destroy", "skyhip_frame_bound", "skyhip_process_batch", "skyhip_process_device",
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
-    "skyhip_last_hip_error",
+    "skyhip_last_hip_error", "skyhip_debug_prof",
 )
 
 
@@ -72,6 +72,8 @@ def load() -> C.CDLL:
     lib.skyhip_reset_timing.restype = None
     lib.skyhip_selftest.argtypes = [vp]
     lib.skyhip_selftest.restype = C.c_int
+    lib.skyhip_debug_prof.argtypes = [vp, vp]
+    lib.skyhip_debug_prof.restype = C.c_int
     lib.skyhip_strerror.argtypes = [C.c_int]
     lib.skyhip_strerror.restype = C.c_char_p
     lib.skyhip_last_hip_error.argtypes = [vp]

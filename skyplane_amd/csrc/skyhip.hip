@@ -144,6 +144,7 @@ struct skyhip_ctx {
     skyhip_timing tm;
     char hip_err[256];
     uint32_t* d_self = nullptr;
+    sky_u64* d_prof = nullptr;   // SKY_PROF builds only
 };
 
 #define HIPCHK(ctx, expr)                                                                             \
@@ -341,6 +342,11 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
             la.in = (const uint8_t*)d_in; la.in_off = c->d_in_off.p + c0; la.in_len = c->d_in_len.p + c0; la.blk_prefix = c->d_blk_prefix.p + c0;
             la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch.p; la.csize = c->d_csize.p;
             { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing experiments only
+            la.prof = nullptr;
+#if SKY_PROF
+            if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8)); }
+            la.prof = c->d_prof;
+#endif
             SkyFrameArgs fa;
             fa.in = la.in; fa.in_off = la.in_off; fa.in_len = la.in_len; fa.blk_prefix = la.blk_prefix; fa.n_chunks = la.n_chunks; fa.n_blocks = nb;
             fa.scratch = c->d_scratch.p; fa.csize = c->d_csize.p; fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p + c0;
@@ -445,6 +451,17 @@ int skyhip_dedup_reset(skyhip_ctx* c) {
 #else
     return SKYHIP_E_INVAL;
 #endif
+}
+
+// SKY_PROF builds: read (and clear) the accumulated s_memtime phase counters; zeros in the shipping build.
+int skyhip_debug_prof(skyhip_ctx* c, uint64_t out[16]) {
+    if (!c || !out) return SKYHIP_E_INVAL;
+    memset(out, 0, 16 * 8);
+    if (c->d_prof) {
+        HIPCHK(c, hipMemcpy(out, c->d_prof, 16 * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8));
+    }
+    return SKYHIP_OK;
 }
 
 int skyhip_selftest(skyhip_ctx* c) {

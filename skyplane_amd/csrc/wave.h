@@ -79,6 +79,11 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+// keep a prefetched value alive up to this point (the load warms L2/L1 for a later batch; nothing reads it)
+SKY_DEV void sky_keep(uint32_t v) { asm volatile("" ::"v"(v)); }
+#define SKY_RESTRICT __restrict__
+// shader clock (s_memtime) for the SKY_PROF phase-timing build only
+SKY_DEV sky_u64 sky_clock() { sky_u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
 // tell the compiler a value is wave-uniform (keeps it in SGPRs; folds away when it already is)
 SKY_DEV uint32_t sky_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // bit `lane` of a wave-uniform mask as a per-lane predicate: the SGPR pair IS the predicate (no shifts)
@@ -92,8 +97,12 @@ SKY_DEV uint32_t sky_ffbl32(uint32_t x) { return (uint32_t)(__builtin_ffs((int)x
 // one instruction: the hardware already returns -1 for zero, which C's ctz/ffs cannot express without a select
 SKY_DEV uint32_t sky_ffbl32(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 #endif
-// index of the highest set bit, 0xFFFFFFFF for x == 0
-SKY_DEV uint32_t sky_flbit32(uint32_t x) { return x ? 31u - (uint32_t)__builtin_clz(x) : 0xFFFFFFFFu; }
+// leading-zero count, 0xFFFFFFFF for x == 0 (v_ffbh_u32 semantics on both builds)
+#ifdef SKY_EMU
+SKY_DEV uint32_t sky_ffbh32(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xFFFFFFFFu; }
+#else
+SKY_DEV uint32_t sky_ffbh32(uint32_t x) { uint32_t r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#endif
 
 // ---- helpers common to both builds ---------------------------------------------------------------
 // Unaligned little-endian loads.  gfx950 under amdhsa runs with unaligned access mode enabled, so the

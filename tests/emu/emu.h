@@ -60,6 +60,9 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+SKY_DEV void sky_keep(uint32_t) {}
+#define SKY_RESTRICT
+SKY_DEV sky_u64 sky_clock() { return 0; }
 SKY_DEV uint32_t sky_uniform(uint32_t v) { return v; }   // uniform by contract: nothing to do
 SKY_DEV bool sky_lanebit(sky_u64 uniform_mask) { return (uniform_mask >> (emu_cur->tid & 63)) & 1ull; }
 

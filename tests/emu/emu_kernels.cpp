@@ -44,7 +44,7 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         std::vector<uint32_t> csize(nb ? nb : 1), word(nb ? nb : 1);
         std::vector<sky_u64> bdst(nb ? nb : 1), flen(n);
         SkyLz4Args la; la.in = in; la.in_off = off.data(); la.in_len = len.data(); la.blk_prefix = prefix.data();
-        la.n_chunks = (uint32_t)n; la.n_blocks = nb; la.scratch = scratch.data(); la.csize = csize.data(); la.ablate = 0;
+        la.n_chunks = (uint32_t)n; la.n_blocks = nb; la.scratch = scratch.data(); la.csize = csize.data(); la.ablate = 0; la.prof = nullptr;
         if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
         SkyFrameArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.blk_prefix = prefix.data(); fa.n_chunks = (uint32_t)n;
         fa.n_blocks = nb; fa.scratch = scratch.data(); fa.csize = csize.data(); fa.out = out; fa.out_off = ooff.data(); fa.frame_len = flen.data();
@@ -60,7 +60,7 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
 // raw single-block entry (no frame): returns compressed size
 uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_SLOT bytes */) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
-    SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0;
+    SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
     emu_launch(1, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
     return cs;
 }
