@@ -36,6 +36,10 @@ extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) sky_gear_candidat
     sky_gear_candidates_body(a, smem);
 }
 extern "C" __global__ void __launch_bounds__(64) sky_gear_select(SkyGearArgs a) { sky_gear_select_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_seg_prefix(SkySegPrefixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_seg_prefix_body(a, smem);
+}
 extern "C" __global__ void __launch_bounds__(64) sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_insert(SkyDedupArgs a) { sky_dedup_insert_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_resolve(SkyDedupArgs a) { sky_dedup_resolve_body(a); }
@@ -116,6 +120,10 @@ template <typename T> struct PinBuf {
 };
 
 }  // namespace
+
+#ifdef SKY_WITH_CDC
+#include "cdc_host.inc"
+#endif
 
 struct skyhip_ctx {
     int dev = 0;
@@ -237,6 +245,9 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, c->d_blk_word.ensure(nb));
         HIPCHK(c, c->d_blk_dst.ensure(nb));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_compress, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4_LDS_BYTES));
+#ifdef SKY_WITH_CDC
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
+#endif
         return 0;
     }();
     if (rc) { skyhip_destroy(c); return rc; }
@@ -377,6 +388,9 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
     HIPCHK(c, hipStreamSynchronize(c->s_cdc));
     (void)hipEventDestroy(meta_ready);
     ev_collect(c);
+#ifdef SKY_WITH_CDC
+    if (flags & SKYHIP_F_CDC) { int frc = sky_cdc_finish(&c->cdc); if (frc) return frc; }
+#endif
     if (flags & SKYHIP_F_LZ4) {
         for (size_t i = 0; i < N; i++) {
             c->tm.lz4_out_bytes += c->h_frame_len.p[i];

@@ -109,7 +109,7 @@ class SkyHipContext:
         out_cap = np.ascontiguousarray(out_cap, np.uint64)
         out_len = np.zeros(n, np.uint64)
         md5 = np.zeros((n, 16), np.uint8) if (flags & F_MD5 and want_md5) else None
-        rc = self._lib.skyhip_process_device(self._h, n, C.c_void_p(d_in), in_off.ctypes.data, in_len.ctypes.data, C.c_void_p(d_out),
+        rc = self._lib.skyhip_process_device(self._h, n, C.c_void_p(d_in), in_off.ctypes.data, in_len.ctypes.data, C.c_void_p(d_out) if d_out else None,
                                              out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
                                              md5.ctypes.data if md5 is not None else None, flags)
         self._check(rc)

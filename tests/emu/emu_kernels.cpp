@@ -67,4 +67,55 @@ uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_S
 
 uint32_t emu_slot_bytes(void) { return SKY_LZ4_SLOT; }
 
+#ifdef SKY_WITH_CDC
+static void k_gcand(void* a, uint8_t* smem) { sky_gear_candidates_body(*(SkyGearArgs*)a, smem); }
+static void k_gsel(void* a, uint8_t*) { sky_gear_select_body(*(SkyGearArgs*)a); }
+static void k_segpre(void* a, uint8_t* smem) { sky_seg_prefix_body(*(SkySegPrefixArgs*)a, smem); }
+static void k_segmd5(void* a, uint8_t*) { sky_segment_md5_body(*(SkySegMd5Args*)a); }
+static void k_dins(void* a, uint8_t*) { sky_dedup_insert_body(*(SkyDedupArgs*)a); }
+static void k_dres(void* a, uint8_t*) { sky_dedup_resolve_body(*(SkyDedupArgs*)a); }
+
+// Mirrors sky_cdc_run's launch sequence.  gear: 256 x u64 table (the caller passes the ORACLE's table so a
+// generator mismatch shows up in the GPU tests, not here).  Returns total segments or <0.
+long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, int n, const uint64_t* gear, uint32_t* seg_prefix_out,
+             uint32_t* seg_end_out, size_t seg_cap, uint8_t* fps_out, uint64_t* first_seen_out, uint64_t* key_lo, uint64_t* key_hi,
+             uint64_t* first, uint32_t slots_log2, uint64_t seg_base, int dedup, uint32_t* cand_cnt_out) {
+    std::vector<sky_u64> off(in_off, in_off + n);
+    std::vector<uint32_t> len(n), tile_prefix(n + 1), cut_prefix(n + 1), ncuts(n), seg_prefix(n + 1);
+    uint32_t tiles = 0, slots = 0;
+    for (int i = 0; i < n; i++) {
+        len[i] = (uint32_t)in_len[i]; tile_prefix[i] = tiles; cut_prefix[i] = slots;
+        tiles += (len[i] + SKY_GEAR_TILE - 1) / SKY_GEAR_TILE; slots += len[i] / SKY_CDC_MIN + 2;
+    }
+    tile_prefix[n] = tiles; cut_prefix[n] = slots;
+    std::vector<uint32_t> cand((size_t)(tiles ? tiles : 1) * SKY_GEAR_CAND_CAP), cand_cnt(tiles ? tiles : 1), cuts(slots), seg_end(slots), seg_slot(slots), err(4, 0);
+    std::vector<uint8_t> fps((size_t)slots * 16);
+    std::vector<sky_u64> fs(slots);
+    SkyGearArgs ga; ga.in = in; ga.in_off = off.data(); ga.in_len = len.data(); ga.tile_prefix = tile_prefix.data(); ga.n_chunks = (uint32_t)n; ga.n_tiles = tiles;
+    ga.gear = (const sky_u64*)gear; ga.cand = cand.data(); ga.cand_cnt = cand_cnt.data(); ga.cut_prefix = cut_prefix.data(); ga.cuts = cuts.data(); ga.n_cuts = ncuts.data();
+    if (tiles) emu_launch(tiles, SKY_GEAR_THREADS, SKY_GEAR_LDS_BYTES, k_gcand, &ga);
+    if (cand_cnt_out) for (uint32_t t = 0; t < tiles; t++) cand_cnt_out[t] = cand_cnt[t];
+    emu_launch((n + 63) / 64, 64, 0, k_gsel, &ga);
+    SkySegPrefixArgs pa; pa.n_cuts = ncuts.data(); pa.seg_prefix = seg_prefix.data(); pa.n_chunks = (uint32_t)n;
+    emu_launch(1, 256, 64, k_segpre, &pa);
+    const uint32_t total = seg_prefix[n];
+    if (total > seg_cap) return -5;
+    SkySegMd5Args ma; ma.in = in; ma.in_off = off.data(); ma.cut_prefix = cut_prefix.data(); ma.cuts = cuts.data(); ma.seg_prefix = seg_prefix.data();
+    ma.n_chunks = (uint32_t)n; ma.max_segs = slots; ma.fps = fps.data(); ma.seg_end = seg_end.data();
+    emu_launch((slots + 63) / 64, 64, 0, k_segmd5, &ma);
+    if (dedup) {
+        SkyDedupArgs da; da.key_lo = (sky_u64*)key_lo; da.key_hi = (sky_u64*)key_hi; da.first = (sky_u64*)first; da.slot_mask = (1u << slots_log2) - 1u;
+        da.fps = fps.data(); da.seg_total = &seg_prefix[n]; da.max_segs = slots; da.seg_base = seg_base; da.seg_slot = seg_slot.data();
+        da.first_seen = fs.data(); da.err = err.data();
+        emu_launch((slots + 255) / 256, 256, 0, k_dins, &da);
+        emu_launch((slots + 255) / 256, 256, 0, k_dres, &da);
+        if (err[0]) return -7;
+    }
+    for (int i = 0; i <= n; i++) seg_prefix_out[i] = seg_prefix[i];
+    for (uint32_t i = 0; i < total; i++) { seg_end_out[i] = seg_end[i]; if (dedup) first_seen_out[i] = fs[i]; }
+    memcpy(fps_out, fps.data(), (size_t)total * 16);
+    return (long)total;
+}
+#endif
+
 }  // extern "C"

@@ -23,6 +23,8 @@ def lib() -> C.CDLL:
         l.emu_lz4_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.emu_lz4_block.restype = C.c_uint32
         l.emu_slot_bytes.restype = C.c_uint32
+        l.emu_cdc.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+        l.emu_cdc.restype = C.c_long
         _lib = l
     return _lib
 
@@ -64,3 +66,42 @@ def process(chunks, flags=3, blk_skew=0):
         if flags & 1:
             assert (out[end:nxt] == 0xEE).all(), f"frame {i} wrote past its length"
     return frames, [md5[i].tobytes() for i in range(n)], cs[:nb]
+
+
+class EmuCdc:
+    """CDC + fingerprints + dedup under the emulator; keeps the dedup table across calls like a skyhip context."""
+
+    def __init__(self, slots_log2=14):
+        self.slots_log2 = slots_log2
+        self.key_lo = np.zeros(1 << slots_log2, np.uint64)
+        self.key_hi = np.zeros(1 << slots_log2, np.uint64)
+        self.first = np.full(1 << slots_log2, 0xFFFFFFFFFFFFFFFF, np.uint64)
+        self.seg_base = 0
+
+    def run(self, chunks, gear, dedup=True):
+        n = len(chunks)
+        lens = np.array([len(c) for c in chunks], np.uint64)
+        in_off = np.zeros(n, np.uint64)
+        pos = 0
+        for i, c in enumerate(chunks):
+            in_off[i] = pos
+            pos += (len(c) + 63) & ~63
+        buf = np.zeros(max(pos, 64) + 64, np.uint8)
+        for i, c in enumerate(chunks):
+            buf[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+        cap = int(sum(len(c) // 4096 + 2 for c in chunks))
+        prefix = np.zeros(n + 1, np.uint32)
+        seg_end = np.zeros(cap, np.uint32)
+        fps = np.zeros((cap, 16), np.uint8)
+        first = np.zeros(cap, np.uint64)
+        ntiles = int(sum((len(c) + 32767) // 32768 for c in chunks))
+        cc = np.zeros(max(ntiles, 1), np.uint32)
+        gear = np.ascontiguousarray(gear, np.uint64)
+        tot = lib().emu_cdc(buf.ctypes.data, in_off.ctypes.data, lens.ctypes.data, n, gear.ctypes.data, prefix.ctypes.data, seg_end.ctypes.data, cap,
+                            fps.ctypes.data, first.ctypes.data, self.key_lo.ctypes.data, self.key_hi.ctypes.data, self.first.ctypes.data,
+                            self.slots_log2, self.seg_base, int(dedup), cc.ctypes.data)
+        assert tot >= 0, tot
+        base = self.seg_base
+        if dedup:
+            self.seg_base += tot
+        return prefix, seg_end[:tot], fps[:tot], (first[:tot] if dedup else None), base, cc[:ntiles]

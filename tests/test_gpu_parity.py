@@ -131,3 +131,83 @@ def test_device_resident_batch_matches_oracle(ctx):
         assert ref.lz4f_decompress(f, cb) == raw, i
     t = ctx.timing()
     assert t.lz4_ms > 0 and t.md5_ms > 0 and t.lz4_in_bytes >= n * cb
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Gear CDC + segment fingerprints + dedup table (new capability; spec = oracle/skyoracle.c, parity unpinned)
+# ---------------------------------------------------------------------------------------------------------
+def _cdc_expect(chunks):
+    cuts = [ref.gear_cdc(c) for c in chunks]
+    fps = []
+    for c, cu in zip(chunks, cuts):
+        st = 0
+        for e in cu:
+            fps.append(hashlib.md5(bytes(c[st:int(e)])).digest())
+            st = int(e)
+    return cuts, fps
+
+
+def test_cdc_fingerprints_dedup_match_spec(small_cases):
+    from skyplane_amd import hip_ops
+
+    with hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=8) as c:
+        flags = hip_ops.F_CDC | hip_ops.F_DEDUP | hip_ops.F_MD5 | hip_ops.F_LZ4
+        seen = []
+        for batch in ([synth.dedup_stream(8 << 20).tobytes(), small_cases["mixed_200k"], b"", bytes(100_000), small_cases["rand_4096"]],
+                      [small_cases["mixed_200k"], synth.dedup_stream(1 << 20, config_id=5).tobytes(), bytes(100_000)]):
+            res = c.process_batch(batch, flags=flags)
+            cuts, efps = _cdc_expect(batch)
+            for d, r, cu in zip(batch, res, cuts):
+                assert (r.cuts == cu).all() and r.md5 == hashlib.md5(d).digest() and ref.lz4f_decompress(r.frame, len(d)) == d
+            prefix, gcuts, fps, first, base = c.cdc_results(len(batch), [len(b) for b in batch])
+            assert base == len(seen) and int(prefix[-1]) == len(efps)
+            assert [fps[i].tobytes() for i in range(len(fps))] == efps
+            allfp = seen + efps
+            exp = ref.dedup_first(np.frombuffer(b"".join(allfp), np.uint8).reshape(-1, 16))
+            assert (exp[len(seen):] == first).all()
+            seen = allfp
+        dup = float((first != np.arange(base, base + len(first))).mean())
+        assert dup > 0.3          # the second batch repeats earlier content
+        c.dedup_reset()
+        res = c.process_batch([small_cases["mixed_200k"]], flags=hip_ops.F_CDC | hip_ops.F_DEDUP)
+        _, _, _, first, base = c.cdc_results(1, [200_000])
+        assert base == 0 and (first == np.arange(len(first))).all()
+
+
+@pytest.mark.parametrize("n", [1, 64, 4096, 4097, 32768, 32769, 65537, 1 << 20])
+def test_cdc_ragged(ctx, n):
+    from skyplane_amd import hip_ops
+
+    rng = synth.rng_for(3, n)
+    chunks = [synth.gen_random(rng, n).tobytes(), synth.gen_text(rng, n).tobytes(), bytes(n)]
+    res = ctx.process_batch(chunks, flags=hip_ops.F_CDC)
+    for c, r in zip(chunks, res):
+        assert (r.cuts == ref.gear_cdc(c)).all()
+
+
+def test_cdc_device_path_config3_stream(ctx):
+    """Config 3 shape: 50 %-duplicate synthetic stream as 8 MiB chunks, device resident; cut points, duplicate
+    fraction and first-seen indices equal the CPU spec."""
+    from skyplane_amd import hip_ops
+
+    cb = synth.CHUNK_BYTES
+    n = 6
+    host = synth.dedup_stream(n * cb, dup_fraction=0.5, config_id=3)
+    d_in = torch.from_numpy(host).cuda()
+    in_off = np.arange(n, dtype=np.uint64) * cb
+    in_len = np.full(n, cb, np.uint64)
+    zero = np.zeros(n, np.uint64)
+    ctx.dedup_reset()
+    ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, flags=hip_ops.F_CDC | hip_ops.F_DEDUP)
+    prefix, cuts, fps, first, base = ctx.cdc_results(n, in_len)
+    chunks = [host[i * cb:(i + 1) * cb] for i in range(n)]
+    ecuts, efps = _cdc_expect(chunks)
+    assert np.concatenate(ecuts).tolist() == cuts.tolist()
+    assert [fps[i].tobytes() for i in range(len(fps))] == efps
+    exp = ref.dedup_first(fps)
+    assert (exp == first).all()
+    dup_bytes = 0
+    seg_len = np.diff(np.concatenate([[0], np.concatenate(ecuts)]))
+    seg_len = np.where(seg_len > 0, seg_len, np.concatenate(ecuts))  # first segment of each chunk
+    dup_bytes = int(seg_len[first != np.arange(len(first))].sum())
+    assert dup_bytes > 0
