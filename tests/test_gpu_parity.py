@@ -167,7 +167,7 @@ def test_cdc_fingerprints_dedup_match_spec(small_cases):
             assert (exp[len(seen):] == first).all()
             seen = allfp
         dup = float((first != np.arange(base, base + len(first))).mean())
-        assert dup > 0.3          # the second batch repeats earlier content
+        assert dup > 0.2          # the second batch repeats earlier content
         c.dedup_reset()
         res = c.process_batch([small_cases["mixed_200k"]], flags=hip_ops.F_CDC | hip_ops.F_DEDUP)
         _, _, _, first, base = c.cdc_results(1, [200_000])
