@@ -1,0 +1,54 @@
+"""Program-node class for the new operator, following skyplane/gateway/gateway_program.py:6-97: every attribute
+of the node is serialised into the program JSON (:21-25) -- that is how the operator gets its knobs -- and
+``create_operator`` is the body of the one ``elif op["op_type"] == "gpu_compress"`` branch a maintainer adds to
+GatewayDaemon.create_gateway_operators (skyplane/gateway/gateway_daemon.py:182-268; unknown op_type raises
+ValueError at :267-268)."""
+import json
+
+
+class GatewayOperator:
+    def __init__(self, op_type):
+        self.op_type = op_type
+        self.children = []
+        self.handle = None
+
+    def add_children(self, children):
+        self.children.extend(children)
+
+    def add_child(self, child):
+        self.children.append(child)
+
+    def set_handle(self, handle: str):
+        self.handle = handle
+
+    def to_dict(self):
+        return {**self.__dict__, **{"children": [c.to_dict() for c in self.children]}}
+
+    def to_json(self):
+        return json.dumps(self.to_dict())
+
+    def __repr__(self):
+        return self.to_json()
+
+
+class GatewayGpuCompress(GatewayOperator):
+    def __init__(self, num_workers: int = 1, max_batch: int = 8, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False):
+        super().__init__("gpu_compress")
+        self.num_workers = num_workers      # one forked worker per GPU is the intended setting
+        self.max_batch = max_batch
+        self.max_chunk_mb = max_chunk_mb
+        self.compute_md5 = compute_md5
+        self.cdc = cdc
+        self.dedup = dedup
+
+
+def create_operator(op: dict, handle: str, region: str, input_queue, output_queue, error_event, error_queue, chunk_store):
+    """Instantiate the runtime operator from its program-JSON dict (handle = op_type + "_" + handle, daemon :150)."""
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress
+
+    if op["op_type"] != "gpu_compress":
+        raise ValueError(f"Unsupported op_type {op['op_type']}")   # same failure mode as gateway_daemon.py:267-268
+    return GatewayHipCompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
+                              error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 8),
+                              max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, compute_md5=op.get("compute_md5", True), cdc=op.get("cdc", False),
+                              dedup=op.get("dedup", False))

@@ -1,0 +1,223 @@
+"""Mirror of the reference's operator base class (skyplane/gateway/operators/gateway_operator.py:32-122) and the
+GPU compress+hash operator that BASELINE.json's north_star asks for ("rewritten compress operator under
+skyplane/gateway/operators").
+
+GatewayOperator keeps the reference contract exactly:
+  * ``start_workers`` forks ``n_processes`` ``Process(target=self.worker_loop, args=(i,)+self.args)`` (:66-70)
+  * ``stop_workers`` sets the per-worker exit flags and joins (:72-77)
+  * ``worker_loop``: get_nowait -> log in_progress -> ``process`` -> True: log complete + output_queue.put,
+    False: re-queue after 0.1 s, exception: traceback to error_queue + error_event.set() (:79-115)
+  * ``worker_exit`` hook (:117-118), abstract ``process`` (:120-122)
+
+GatewayHipCompress replaces the two CPU call sites of the source gateway's hot path --
+``lz4.frame.compress`` inside GatewaySender.process (:358-361) and the ``hashlib.md5`` loop requested by
+GatewayObjStoreReadOperator.process (:555-565, result dropped at :577-582) -- with one batched call into
+libskyhip.so.  It overrides ``worker_loop`` (the base loop sleeps 0.1 s per chunk and
+busy-spins when idle, capping one worker below 80 MiB/s) to drain up to ``max_batch`` requests per iteration.
+There is no CPU fallback: if the HIP extension or the GPU is missing the worker raises, which the loop turns
+into the reference's error path (error_queue + error_event -> daemon-wide stop).
+"""
+from __future__ import annotations
+
+import os
+import queue
+import time
+import traceback
+from abc import ABC, abstractmethod
+from multiprocessing import Event, Process, Queue
+from typing import Callable, List, Optional
+
+from skyplane_amd.chunk import ChunkRequest, ChunkState
+from skyplane_amd.gateway.chunk_store import ChunkStore
+from skyplane_amd.gateway.gateway_queue import GatewayQueue
+
+
+class GatewayOperator(ABC):
+    yield_sleep_s = 0.1  # gateway_operator.py:102 "yield ?"
+
+    def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
+                 chunk_store: ChunkStore, n_processes: Optional[int] = 1):
+        self.handle = handle
+        self.region = region
+        self.input_queue = input_queue
+        self.output_queue = output_queue
+        self.chunk_store = chunk_store
+        self.error_event = error_event
+        self.error_queue = error_queue
+        self.n_processes = n_processes
+        self.args = ()
+        self.processes: List[Process] = []
+        self.exit_flags = [Event() for _ in range(self.n_processes)]
+        self.worker_id: Optional[int] = None
+
+    def start_workers(self):
+        for i in range(self.n_processes):
+            p = Process(target=self.worker_loop, args=(i,) + self.args)
+            p.start()
+            self.processes.append(p)
+
+    def stop_workers(self):
+        for i in range(self.n_processes):
+            self.exit_flags[i].set()
+        for p in self.processes:
+            p.join()
+        self.processes = []
+
+    def worker_loop(self, worker_id: int, *args):
+        self.worker_id = worker_id
+        while not self.exit_flags[worker_id].is_set() and not self.error_event.is_set():
+            try:
+                try:
+                    chunk_req = self.input_queue.get_nowait(self.handle)
+                except queue.Empty:
+                    continue
+                self.chunk_store.log_chunk_state(chunk_req, ChunkState.in_progress, operator_handle=self.handle, worker_id=worker_id)
+                succ = self.process(chunk_req, *args)
+                if succ:
+                    self.chunk_store.log_chunk_state(chunk_req, ChunkState.complete, operator_handle=self.handle, worker_id=worker_id)
+                    if self.output_queue is not None:
+                        self.output_queue.put(chunk_req)
+                    time.sleep(self.yield_sleep_s)
+                else:
+                    time.sleep(0.1)
+                    self.input_queue.put(chunk_req)
+            except Exception:
+                self.error_queue.put(traceback.format_exc())
+                self.error_event.set()
+                self.exit_flags[worker_id].set()
+        self.worker_exit(worker_id)
+
+    def worker_exit(self, worker_id: int):
+        pass
+
+    @abstractmethod
+    def process(self, chunk_req: ChunkRequest, **args):
+        pass
+
+
+def _default_context_factory(device_id: int, max_chunk_bytes: int, max_batch: int):
+    from skyplane_amd import hip_ops  # imported in the forked worker only: HIP must not be initialised in the daemon parent
+
+    return hip_ops.SkyHipContext(device_id=device_id, max_chunk_bytes=max_chunk_bytes, max_batch=max_batch)
+
+
+def visible_gpu_count() -> int:
+    """Number of GPUs without touching the HIP runtime in this (possibly parent) process."""
+    env = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if env:
+        return len([x for x in env.split(",") if x.strip() != ""])
+    try:
+        return max(1, len([d for d in os.listdir("/sys/class/kfd/kfd/topology/nodes")
+                           if open(f"/sys/class/kfd/kfd/topology/nodes/{d}/gpu_id").read().strip() not in ("", "0")]))
+    except OSError:
+        return 1
+
+
+class GatewayHipCompress(GatewayOperator):
+    """op_type "gpu_compress": sits on the edge read_object_store -> [mux] -> send of the source gateway.
+
+    For every ChunkRequest the raw bytes are at ``chunk_store.get_chunk_file_path(chunk_id)``.  The operator
+    leaves that file untouched (GatewaySender asserts its size, :352) and writes next to it
+      <id>.chunk.lz4f  -- a conformant LZ4 frame of the chunk (what lz4.frame.compress would have produced, up
+                          to compressed bytes; lz4.frame.decompress at gateway_receiver.py:196 returns the raw bytes)
+      <id>.chunk.md5   -- hex MD5 of the raw bytes (Chunk.md5_hash cannot carry bytes through the sender's
+                          json.dumps at :299)
+    and reports ``compressed_size_bytes`` / ``uncompressed_size_bytes`` in the status metadata consumed by the
+    reference's compression profile endpoint (gateway_daemon_api.py:129-134, :340-354).
+    Worker i binds GPU ``device_ids[i % len(device_ids)]``: chunks are independent, so the N GPUs of a node are N
+    workers pulling from one queue -- no collective anywhere.
+    """
+
+    def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
+                 chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 8, max_chunk_bytes: int = 64 << 20,
+                 device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
+                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None):
+        super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
+        self.max_batch = int(max_batch)
+        self.max_chunk_bytes = int(max_chunk_bytes)
+        self.device_ids = list(device_ids) if device_ids is not None else list(range(visible_gpu_count()))
+        self.compute_md5 = compute_md5
+        self.cdc = cdc
+        self.dedup = dedup
+        self.idle_sleep_s = idle_sleep_s
+        self._context_factory = context_factory or _default_context_factory
+        self._ctx = None
+
+    # -- process-local ---------------------------------------------------------------------------------
+    def _context(self):
+        if self._ctx is None:
+            wid = self.worker_id or 0
+            dev = self.device_ids[wid % len(self.device_ids)]
+            self._ctx = self._context_factory(dev, self.max_chunk_bytes, self.max_batch)
+        return self._ctx
+
+    def _flags(self) -> int:
+        return 1 | (2 if self.compute_md5 else 0) | (4 if self.cdc else 0) | (8 if self.dedup and self.cdc else 0)
+
+    def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
+        datas = []
+        for cr in chunk_reqs:
+            path = self.chunk_store.get_chunk_file_path(cr.chunk.chunk_id)
+            with open(path, "rb") as f:
+                data = f.read()
+            # same invariant GatewaySender.process asserts at gateway_operator.py:352
+            assert len(data) == cr.chunk.chunk_length_bytes, f"chunk {cr.chunk.chunk_id} has size {len(data)} but should be {cr.chunk.chunk_length_bytes}"
+            datas.append(data)
+        results = self._context().process_batch(datas, flags=self._flags())
+        self._last_metadata = []
+        for cr, data, res in zip(chunk_reqs, datas, results):
+            cid = cr.chunk.chunk_id
+            tmp = self.chunk_store.get_compressed_file_path(cid).with_suffix(".tmp")
+            with open(tmp, "wb") as f:
+                f.write(res.frame)
+            os.replace(tmp, self.chunk_store.get_compressed_file_path(cid))   # the sender never sees a partial frame
+            meta = {"compressed_size_bytes": len(res.frame), "uncompressed_size_bytes": len(data)}
+            if res.md5 is not None:
+                self.chunk_store.get_digest_file_path(cid).write_text(res.md5.hex())
+                meta["md5_hex"] = res.md5.hex()
+            if res.cuts is not None:
+                meta["cdc_segments"] = int(len(res.cuts))
+            self._last_metadata.append(meta)
+        return [True] * len(chunk_reqs)
+
+    def process(self, chunk_req: ChunkRequest, **args):
+        return self.process_batch([chunk_req])[0]
+
+    def worker_loop(self, worker_id: int, *args):
+        self.worker_id = worker_id
+        while not self.exit_flags[worker_id].is_set() and not self.error_event.is_set():
+            try:
+                batch: List[ChunkRequest] = []
+                while len(batch) < self.max_batch:
+                    try:
+                        batch.append(self.input_queue.get_nowait(self.handle))
+                    except queue.Empty:
+                        break
+                if not batch:
+                    time.sleep(self.idle_sleep_s)      # no busy spin (reference :84-88 spins)
+                    continue
+                for cr in batch:
+                    self.chunk_store.log_chunk_state(cr, ChunkState.in_progress, operator_handle=self.handle, worker_id=worker_id)
+                oks = self.process_batch(batch)
+                retry = []
+                for cr, ok, meta in zip(batch, oks, self._last_metadata):
+                    if ok:
+                        self.chunk_store.log_chunk_state(cr, ChunkState.complete, operator_handle=self.handle, worker_id=worker_id, metadata=meta)
+                        if self.output_queue is not None:
+                            self.output_queue.put(cr)
+                    else:
+                        retry.append(cr)
+                if retry:
+                    time.sleep(0.1)
+                    for cr in retry:
+                        self.input_queue.put(cr)
+            except Exception:
+                self.error_queue.put(traceback.format_exc())
+                self.error_event.set()
+                self.exit_flags[worker_id].set()
+        self.worker_exit(worker_id)
+
+    def worker_exit(self, worker_id: int):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None

@@ -1,0 +1,40 @@
+"""Sender cooperation (SURVEY.md 8b "unavoidable"): what GatewaySender.process must do differently when the
+gpu_compress operator ran upstream.  The reference sender re-reads the raw chunk, compresses it itself and only
+then sets is_compressed (skyplane/gateway/operators/gateway_operator.py:343-372).  ``wire_payload`` is the
+replacement for those lines: ship the pre-compressed sidecar when present, otherwise the raw bytes; the header,
+the receiver (gateway_receiver.py:142-237) and chunk.py stay untouched.  INTEGRATION.md shows the ~10-line patch."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
+from skyplane_amd.gateway.chunk_store import ChunkStore
+
+
+def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int) -> Tuple[WireProtocolHeader, bytes]:
+    chunk = chunk_req.chunk
+    sidecar = chunk_store.get_compressed_file_path(chunk.chunk_id)
+    if sidecar.exists():
+        data = sidecar.read_bytes()
+        header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=len(data),
+                                      raw_wire_length=chunk.chunk_length_bytes, is_compressed=True)
+        return header, data
+    data = chunk_store.get_chunk_file_path(chunk.chunk_id).read_bytes()
+    assert len(data) == chunk.chunk_length_bytes, f"chunk {chunk.chunk_id} has size {len(data)} but should be {chunk.chunk_length_bytes}"
+    header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=len(data), raw_wire_length=len(data), is_compressed=False)
+    return header, data
+
+
+def chunk_digest(chunk_store: ChunkStore, chunk_id: str) -> Optional[bytes]:
+    """The 16-byte digest Chunk.md5_hash is declared to carry (chunk.py:21), read from the side channel."""
+    p = chunk_store.get_digest_file_path(chunk_id)
+    return bytes.fromhex(p.read_text().strip()) if p.exists() else None
+
+
+def cleanup_sidecars(chunk_store: ChunkStore, chunk_id: str):
+    """gateway_daemon_api.py:125-127 unlinks only <id>.chunk; whoever completes the chunk removes the sidecars."""
+    for p in (chunk_store.get_compressed_file_path(chunk_id), chunk_store.get_digest_file_path(chunk_id)):
+        try:
+            p.unlink()
+        except FileNotFoundError:
+            pass

@@ -1,0 +1,235 @@
+"""Host logic of the gpu_compress operator on a GPU-less box: queue draining, status records, sidecars, error path,
+sender cooperation, program-node registration, C-ABI surface, multi-rank sharding (gloo, world_size 2).
+
+The HIP context is replaced by a TEST DOUBLE that produces frames with the oracle -- that is legal here because this
+file tests plumbing, not arithmetic (the arithmetic is tested through the real C ABI in test_gpu_*.py), and it shows
+the product has no CPU fallback: without the double the worker fails loudly (test_operator_fails_loudly_without_gpu)."""
+import ctypes
+import hashlib
+import os
+import queue as pyqueue
+import re
+import time
+import uuid
+from multiprocessing import Event, Queue
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from skyplane_amd import synth
+from skyplane_amd.chunk import Chunk, ChunkRequest, ChunkState, WireProtocolHeader
+from skyplane_amd.gateway import gateway_program
+from skyplane_amd.gateway.chunk_store import ChunkStore
+from skyplane_amd.gateway.gateway_queue import GatewayANDQueue, GatewayQueue
+from skyplane_amd.gateway.operators import hip_sender
+from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress, GatewayOperator
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+class _OracleContext:
+    """Test double with SkyHipContext's process_batch signature."""
+
+    def __init__(self, device_id, max_chunk_bytes, max_batch):
+        self.device_id = device_id
+        Path(os.environ["SKYTEST_DEVLOG"]).open("a").write(f"{os.getpid()} {device_id}\n")
+
+    def process_batch(self, chunks, flags=3):
+        from skyplane_amd.hip_ops import ChunkResult
+
+        return [ChunkResult(frame=ref.lz4f_compress_port(c), md5=ref.md5(c) if flags & 2 else None) for c in chunks]
+
+    def close(self):
+        pass
+
+
+def _factory(dev, mc, mb):
+    return _OracleContext(dev, mc, mb)
+
+
+def _make_store(tmp_path, n, size=70_000):
+    store = ChunkStore(tmp_path / "chunks")
+    q_in, q_out = GatewayQueue(), GatewayQueue()
+    store.add_partition("0", q_in)
+    reqs = []
+    rng = synth.rng_for(11)
+    for i in range(n):
+        cid = uuid.uuid4().hex
+        data = (synth.gen_text(rng, size) if i % 2 else synth.gen_random(rng, size)).tobytes()
+        store.get_chunk_file_path(cid).write_bytes(data)
+        cr = ChunkRequest(chunk=Chunk(src_key=f"/src/{i}", dest_key=f"{i}", chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
+        reqs.append((cr, data))
+    return store, q_in, q_out, reqs
+
+
+def _drain(q: Queue, n, timeout=30):
+    out, t0 = [], time.time()
+    while len(out) < n and time.time() - t0 < timeout:
+        try:
+            out.append(q.get(timeout=0.2))
+        except pyqueue.Empty:
+            pass
+    return out
+
+
+def test_operator_batches_shards_devices_and_writes_sidecars(tmp_path, monkeypatch):
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    n = 11
+    store, q_in, q_out, reqs = _make_store(tmp_path, n)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "local:test", q_in, q_out, err_ev, err_q, store, n_processes=2, max_batch=4, device_ids=[0, 1],
+                            context_factory=_factory)
+    for cr, _ in reqs:
+        assert store.add_chunk_request(cr)[1]
+    t0 = time.time()
+    op.start_workers()
+    done = _drain(q_out.q, n)
+    elapsed = time.time() - t0
+    op.stop_workers()
+    assert not err_ev.is_set(), err_q.get() if not err_q.empty() else ""
+    assert sorted(c.chunk.chunk_id for c in done) == sorted(cr.chunk.chunk_id for cr, _ in reqs)
+    assert elapsed < n * 0.1, "batched worker_loop must not inherit the reference's 0.1 s/chunk throttle"
+    # two workers -> two devices, round-robin by worker id
+    devs = {int(l.split()[1]) for l in (tmp_path / "dev.log").read_text().split("\n") if l}
+    assert devs == {0, 1}
+    # status records: registered, in_progress, complete(+metadata) per chunk
+    recs = _drain(store.chunk_status_queue, 3 * n)
+    comp = [r for r in recs if r["state"] == "complete"]
+    assert len(comp) == n and all(r["handle"] == "gpu_compress_0" and r["uncompressed_size_bytes"] == 70_000 and r["compressed_size_bytes"] > 0 for r in comp)
+    # sidecars + the cooperating sender's wire bytes; receiver-side checks of gateway_receiver.py:150-218
+    for cr, data in reqs:
+        assert store.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == data           # raw file untouched
+        hdr, payload = hip_sender.wire_payload(store, cr, n_chunks_left_on_socket=0)
+        h2 = WireProtocolHeader.from_bytes(hdr.to_bytes())
+        assert h2.is_compressed and h2.data_len == len(payload) and h2.raw_data_len == len(data)
+        out = ref.lz4f_decompress(payload, h2.raw_data_len)                                 # == lz4.frame.decompress
+        assert out == data and len(out) == h2.raw_data_len
+        assert hip_sender.chunk_digest(store, cr.chunk.chunk_id) == hashlib.md5(data).digest()
+        hip_sender.cleanup_sidecars(store, cr.chunk.chunk_id)
+        hdr, payload = hip_sender.wire_payload(store, cr, 3)                                # no sidecar -> raw, like use_compression=False
+        assert not hdr.is_compressed and payload == data and hdr.n_chunks_left_on_socket == 3
+
+
+def test_operator_error_path_matches_reference(tmp_path, monkeypatch):
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    store, q_in, q_out, reqs = _make_store(tmp_path, 2)
+    store.get_chunk_file_path(reqs[1][0].chunk.chunk_id).write_bytes(b"short")            # size mismatch -> assertion (like :352)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "r", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=8, device_ids=[0], context_factory=_factory)
+    for cr, _ in reqs:
+        store.add_chunk_request(cr)
+    op.start_workers()
+    assert err_ev.wait(20)
+    tb = err_q.get(timeout=5)
+    op.stop_workers()
+    assert "AssertionError" in tb and "should be" in tb
+
+
+def test_operator_fails_loudly_without_gpu(tmp_path):
+    """No test double, no GPU in this container: the worker must raise into the reference's error path, never
+    fall back to a CPU codec."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    store, q_in, q_out, reqs = _make_store(tmp_path, 1)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "r", q_in, q_out, err_ev, err_q, store, n_processes=1, device_ids=[0])
+    store.add_chunk_request(reqs[0][0])
+    op.start_workers()
+    assert err_ev.wait(60)
+    tb = err_q.get(timeout=5)
+    op.stop_workers()
+    assert "SkyHipError" in tb or "ImportError" in tb
+    assert q_out.size() == 0 and not store.get_compressed_file_path(reqs[0][0].chunk.chunk_id).exists()
+
+
+def test_base_operator_contract(tmp_path):
+    class Echo(GatewayOperator):
+        yield_sleep_s = 0.0
+
+        def process(self, chunk_req, **args):
+            return True
+
+    store, q_in, q_out, reqs = _make_store(tmp_path, 3, size=10)
+    err_ev, err_q = Event(), Queue()
+    op = Echo("echo_0", "r", q_in, q_out, err_ev, err_q, store, n_processes=1)
+    for cr, _ in reqs:
+        store.add_chunk_request(cr)
+    op.start_workers()
+    assert len(_drain(q_out.q, 3)) == 3
+    op.stop_workers()
+    states = [r["state"] for r in _drain(store.chunk_status_queue, 9)]
+    assert states.count("registered") == 3 and states.count("in_progress") == 3 and states.count("complete") == 3
+
+
+def test_and_queue_fans_out():
+    q = GatewayANDQueue()
+    q.register_handle("a"); q.register_handle("b")
+    q.put(1)
+    assert q.get_handle_queue("a").q.get(timeout=5) == 1 and q.get_handle_queue("b").q.get(timeout=5) == 1
+    with pytest.raises(ValueError):
+        q.put_nowait(2)
+
+
+def test_program_node_and_registration(tmp_path):
+    node = gateway_program.GatewayGpuCompress(num_workers=8, max_batch=16, cdc=True)
+    node.set_handle("n1")
+    d = node.to_dict()
+    assert d["op_type"] == "gpu_compress" and d["num_workers"] == 8 and d["max_batch"] == 16 and d["cdc"] is True and d["children"] == []
+    store = ChunkStore(tmp_path / "c")
+    op = gateway_program.create_operator(d, "gpu_compress_n1", "r", GatewayQueue(), GatewayQueue(), Event(), Queue(), store)
+    assert isinstance(op, GatewayHipCompress) and op.n_processes == 8 and op.max_batch == 16 and op.cdc
+    with pytest.raises(ValueError):
+        gateway_program.create_operator({"op_type": "nope"}, "h", "r", None, None, None, None, store)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from skyplane_amd import _lib
+
+    lib = _lib.load()
+    header = (ROOT / "include" / "skyhip.h").read_text()
+    declared = set(re.findall(r"\b(skyhip_[a-z_]+)\s*\(", header))
+    assert declared and declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.skyhip_abi_version() == 1
+    assert lib.skyhip_frame_bound(8 << 20) == 8389139          # the reference's worst case for 8 MiB
+    assert lib.skyhip_frame_bound(0) == 19 and lib.skyhip_frame_bound(1) == 24
+    assert b"device" in lib.skyhip_strerror(-6)
+    h = ctypes.c_void_p()
+    assert lib.skyhip_create(0, 0, 1, ctypes.byref(h)) == -1     # argument validation needs no GPU
+
+
+def _gloo_worker(rank, world, port, n_chunks, out_q):
+    import torch.distributed as dist
+
+    from skyplane_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_indices(n_chunks, rank, world)
+    local, worst = shard.timed_region(lambda: time.sleep(0.05 * (rank + 1)), steps=2, dist=dist)
+    out_q.put((rank, mine, local, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_sharding_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 13, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    (r0, s0, l0, w0), (r1, s1, l1, w1) = res
+    assert sorted(s0 + s1) == list(range(13)) and not set(s0) & set(s1) and s0 == list(range(0, 13, 2))
+    assert w0 == pytest.approx(w1) and w0 >= max(l0, l1) - 1e-6 and l1 > l0      # every rank reports the slowest rank's time
