@@ -248,6 +248,14 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
 #ifdef SKY_WITH_CDC
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
 #endif
+        if (getenv("SKYHIP_DEBUG")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sky_lz4_compress, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, (const void*)sky_lz4_compress);
+            fprintf(stderr, "[skyhip] sky_lz4_compress: %d workgroups/CU (x%d waves), %d VGPRs, %zu B static LDS, %d B dynamic LDS, CUs %d, LDS/CU %zu\n", nb,
+                    SKY_LZ4_WAVES, fa.numRegs, fa.sharedSizeBytes, SKY_LZ4_LDS_BYTES, prop.multiProcessorCount, prop.maxSharedMemoryPerMultiProcessor);
+        }
         return 0;
     }();
     if (rc) { skyhip_destroy(c); return rc; }
