@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--unit-mib", type=int, default=256)
     ap.add_argument("--max-batch", type=int, default=512, help="chunks per LZ4 sub-batch (scratch = 8.06 MiB each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cdc", action="store_true", help="configs[2]: add Gear CDC + segment fingerprints + dedup table on a 50 %%-duplicate stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +106,7 @@ def main():
 
     # ---- synthetic stream: unit generated on the host (deterministic), tiled + rotated on the device ----
     t0 = time.perf_counter()
-    unit = synth.silesia_like(unit_bytes, config_id=2)
+    unit = synth.dedup_stream(unit_bytes, dup_fraction=0.5, config_id=3) if args.cdc else synth.silesia_like(unit_bytes, config_id=2)
     d_unit = torch.from_numpy(unit).to(dev)
     d_in = torch.empty(n_chunks * cb, dtype=torch.uint8, device=dev)
     per = unit_bytes // cb
@@ -128,9 +129,11 @@ def main():
     out_cap = np.full(n_chunks, stride, np.uint64)
 
     ctx = hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch)
-    flags = hip_ops.F_LZ4 | hip_ops.F_MD5
+    flags = hip_ops.F_LZ4 | hip_ops.F_MD5 | ((hip_ops.F_CDC | hip_ops.F_DEDUP) if args.cdc else 0)
 
     def step():
+        if args.cdc:
+            ctx.dedup_reset()      # every step sees the stream for the first time
         return ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, flags)
 
     def barrier():
@@ -179,6 +182,26 @@ def main():
                                     "gather": round(tm.gather_ms / args.steps, 3), "md5": round(tm.md5_ms / args.steps, 3)},
             "setup_s": round(gen_s, 1),
         }
+        # HBM-side traffic of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE cannot be collected inside this run
+        # (separate rocprofv3 --pmc passes, scripts/pmc.sh); the committed per-input-byte factors are applied here.
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            t = json.loads(tf.read_text())
+            per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
+            res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
+            res["roofline"]["traffic_source"] = t["source"]
+        if args.cdc:
+            res["config"]["workload"] = res["config"]["workload"].replace("configs[1]", "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table; 50 %-duplicate stream)")
+            res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
+            prefix, cuts, fps, first, base = ctx.cdc_results(n_chunks, in_len)
+            import numpy as _np
+            seg_end = cuts.astype(_np.int64)
+            seg_start = _np.concatenate([[0], seg_end[:-1]])
+            seg_start[prefix[:-1][prefix[:-1] < prefix[1:]].astype(_np.int64)] = 0      # first segment of every chunk starts at 0
+            seg_len = seg_end - seg_start
+            dup = first != _np.arange(base, base + len(first), dtype=_np.uint64)
+            res["config"]["segments"] = int(len(first)); res["config"]["avg_segment_bytes"] = round(float(seg_len.mean()), 1)
+            res["config"]["duplicate_bytes_fraction"] = round(float(seg_len[dup].sum() / seg_len.sum()), 4)
         # spot check (outside the timed region): first and last chunk against the oracle
         import hashlib
 
