@@ -118,7 +118,10 @@ def main():
         rots.append(rot)
         lo = t * unit_bytes
         hi = min(lo + unit_bytes, n_chunks * cb)
-        d_in[lo:hi] = torch.roll(d_unit, -rot)[: hi - lo]
+        tile = torch.roll(d_unit, -rot)[: hi - lo]
+        if args.cdc and t:
+            tile = tile ^ (t & 0xFF)      # keep the unit's internal duplicate structure, make tiles mutually distinct
+        d_in[lo:hi] = tile
     d_out = torch.empty(n_chunks * stride, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
     gen_s = time.perf_counter() - t0
@@ -210,6 +213,8 @@ def main():
         for i in (0, n_chunks - 1):
             t = i * cb // unit_bytes
             raw = np.roll(unit, -rots[t])[(i * cb) % unit_bytes:(i * cb) % unit_bytes + cb]
+            if args.cdc and t:
+                raw = raw ^ np.uint8(t & 0xFF)
             assert md5[i].tobytes() == hashlib.md5(raw).digest(), f"bench spot check: md5 of chunk {i}"
             f = d_out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].cpu().numpy()
             assert ref.lz4f_decompress(f, cb) == raw.tobytes(), f"bench spot check: frame of chunk {i}"

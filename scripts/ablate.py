@@ -33,3 +33,18 @@ for abl in [int(x) for x in os.environ.get("ABLS", "0,1,2,4,5,7,15").split(",")]
             print(f"    {names[i]:28s} {pr[i]/pr[9]:12.0f}  {100.0*pr[i]/tot:5.1f}%")
         print(f"    {'block total':28s} {pr[8]/pr[9]:12.0f}   ({pr[9]} blocks; unattributed {100.0*(tot-sum(pr[:8]))/tot:.1f}%)")
     print(f"ablate={abl:2d} lz4 {t.lz4_ms/2:8.2f} ms  -> {n*cb/ (t.lz4_ms/2e3)/1e9:7.1f} GB/s   gather {t.gather_ms/2:6.2f} ms", flush=True)
+# CDC stage alone (no LZ4/MD5 co-running)
+os.environ["SKYHIP_ABLATE"] = "0"
+zero = np.zeros(n, np.uint64)
+ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_CDC | hip_ops.F_DEDUP)
+ctx.dedup_reset(); ctx.reset_timing()
+for _ in range(2):
+    ctx.dedup_reset()
+    ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_CDC | hip_ops.F_DEDUP)
+t = ctx.timing()
+print(f"cdc alone {t.cdc_ms/2:8.2f} ms -> {n*cb/(t.cdc_ms/2e3)/1e9:7.1f} GB/s", flush=True)
+ctx.reset_timing()
+for _ in range(2):
+    ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_MD5)
+t = ctx.timing()
+print(f"md5 alone {t.md5_ms/2:8.2f} ms ({n} chunks)", flush=True)

@@ -95,7 +95,7 @@ long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, 
     ga.gear = (const sky_u64*)gear; ga.cand = cand.data(); ga.cand_cnt = cand_cnt.data(); ga.cut_prefix = cut_prefix.data(); ga.cuts = cuts.data(); ga.n_cuts = ncuts.data();
     if (tiles) emu_launch(tiles, SKY_GEAR_THREADS, SKY_GEAR_LDS_BYTES, k_gcand, &ga);
     if (cand_cnt_out) for (uint32_t t = 0; t < tiles; t++) cand_cnt_out[t] = cand_cnt[t];
-    emu_launch((n + 63) / 64, 64, 0, k_gsel, &ga);
+    emu_launch(n, 64, 0, k_gsel, &ga);
     SkySegPrefixArgs pa; pa.n_cuts = ncuts.data(); pa.seg_prefix = seg_prefix.data(); pa.n_chunks = (uint32_t)n;
     emu_launch(1, 256, 64, k_segpre, &pa);
     const uint32_t total = seg_prefix[n];
