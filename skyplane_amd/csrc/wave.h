@@ -39,31 +39,27 @@ SKY_DEV void sky_syncthreads() { __syncthreads(); }
 // compile-time ordering of this wave's LDS/global accesses (lanes of one wave execute DS ops in issue order)
 SKY_DEV void sky_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-#ifndef SKY_SCAN_SHFL
-// DPP inclusive add-scan over the 64 lanes: 4 row_shr steps inside each 16-lane row, then
-// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 (gfx9-family DPP controls).
+// DPP inclusive add-scan over the 64 lanes: 4 row_shr steps inside each 16-lane row, then row_bcast:15 into rows
+// 1,3 and row_bcast:31 into rows 2,3 (gfx9-family DPP controls).  Written as six in-place v_add_u32_dpp (hipcc
+// lowers the builtin form to mov+mov_dpp+add per step); "s_nop 1" covers the VALU-write -> DPP-read hazard.
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t x) {
-    int v = (int)x;
-    // bound_ctrl=true (out-of-row source reads 0) lets the compiler fuse each step into one v_add_u32_dpp
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-    return (uint32_t)v;
-}
-#else
-// reference form of the same scan through ds_bpermute (kept for the on-GPU self-test)
-SKY_DEV uint32_t sky_scan_incl_add(uint32_t x) {
-    const int lane = sky_lane();
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = sky_shfl(x, (lane - d) & 63);
-        if (lane >= d) x += t;
-    }
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(x));
     return x;
 }
-#endif
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t x) {
     const int lane = sky_lane();
     for (int d = 1; d < 64; d <<= 1) {
@@ -87,6 +83,9 @@ SKY_DEV void sky_keep(uint32_t v) { asm volatile("" ::"v"(v)); }
 SKY_DEV sky_u64 sky_clock() { sky_u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
 // tell the compiler a value is wave-uniform (keeps it in SGPRs; folds away when it already is)
 SKY_DEV uint32_t sky_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+SKY_DEV sky_u64 sky_uniform64(sky_u64 v) {
+    return (sky_u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((sky_u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
 // bit `lane` of a wave-uniform mask as a per-lane predicate: the SGPR pair IS the predicate (no shifts)
 SKY_DEV bool sky_lanebit(sky_u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 #endif  // SKY_EMU

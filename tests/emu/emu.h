@@ -63,7 +63,8 @@ SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
 SKY_DEV void sky_keep(uint32_t) {}
 #define SKY_RESTRICT
 SKY_DEV sky_u64 sky_clock() { return 0; }
-SKY_DEV uint32_t sky_uniform(uint32_t v) { return v; }   // uniform by contract: nothing to do
+SKY_DEV uint32_t sky_uniform(uint32_t v) { return v; }
+SKY_DEV sky_u64 sky_uniform64(sky_u64 v) { return v; }   // uniform by contract: nothing to do
 SKY_DEV bool sky_lanebit(sky_u64 uniform_mask) { return (uniform_mask >> (emu_cur->tid & 63)) & 1ull; }
 
 // Launch: run `body(args)` for every thread of every workgroup, one workgroup at a time.
