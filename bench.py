@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=0, help="8 MiB chunks per GPU per step (0 = 8192 = 64 GiB if it fits)")
     ap.add_argument("--unit-mib", type=int, default=256)
-    ap.add_argument("--max-batch", type=int, default=512, help="chunks per LZ4 sub-batch (scratch = 8.06 MiB each)")
+    ap.add_argument("--max-batch", type=int, default=2048, help="chunks per LZ4 sub-batch (scratch = 8.06 MiB each; fewer, larger launches = fewer launch tails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cdc", action="store_true", help="configs[2]: add Gear CDC + segment fingerprints + dedup table on a 50 %%-duplicate stream")
     args = ap.parse_args()
