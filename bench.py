@@ -101,6 +101,10 @@ def main():
     n_chunks = args.chunks or 8192
     while n_chunks > 64 and n_chunks * (cb + stride) + scratch + (6 << 30) > free_b:
         n_chunks //= 2
+    if world > 1:   # every rank must process the same number of chunks (weak scaling, value = world x chunks x bytes)
+        nc = torch.tensor([n_chunks], dtype=torch.int64, device=dev)
+        dist.all_reduce(nc, op=dist.ReduceOp.MIN)
+        n_chunks = int(nc.item())
     unit_bytes = min(args.unit_mib << 20, n_chunks * cb)
     unit_bytes -= unit_bytes % cb
 

@@ -360,7 +360,10 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
             SkyLz4Args la;
             la.in = (const uint8_t*)d_in; la.in_off = c->d_in_off.p + c0; la.in_len = c->d_in_len.p + c0; la.blk_prefix = c->d_blk_prefix.p + c0;
             la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch.p; la.csize = c->d_csize.p;
-            { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing experiments only
+            la.ablate = 0;
+#if SKY_ABL
+            { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing-experiment builds only
+#endif
             la.prof = nullptr;
 #if SKY_PROF
             if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8)); }
