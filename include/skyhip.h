@@ -47,6 +47,7 @@ extern "C" {
 #define SKYHIP_E_CAP        -5   /* an output buffer is smaller than skyhip_frame_bound(len) / cut capacity */
 #define SKYHIP_E_NODEVICE   -6   /* no usable gfx950 device */
 #define SKYHIP_E_TABLEFULL  -7   /* dedup table is full */
+#define SKYHIP_E_FORMAT     -8   /* a frame handed to skyhip_decompress_* is malformed or uses an unsupported option */
 
 typedef struct skyhip_ctx skyhip_ctx;   /* opaque: owns device scratch, streams, events, dedup table */
 
@@ -94,6 +95,22 @@ int  skyhip_process_device(skyhip_ctx* ctx, int n,
                            const void* d_in, const uint64_t* in_off, const uint64_t* in_len,
                            void* d_out, const uint64_t* out_off, const uint64_t* out_cap,
                            uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags);
+
+/* LZ4 frame DEcompression -- the destination gateway's mirrored hot loop:
+ *   `data_batch_decompressed = lz4.frame.decompress(to_write)`   skyplane/gateway/operators/gateway_receiver.py:195-201
+ * Accepts frames with a content size and 64 KiB..4 MiB blocks, block-independent (this library's) or block-linked
+ * (python-lz4's default), stored blocks allowed, no checksums/dictionary.  out_len[i] = decoded bytes (== the frame's
+ * content size, which the caller compares with WireProtocolHeader.raw_data_len as gateway_receiver.py:213-218 does).
+ * status[i] (may be NULL) = 0 or a positive decoder code; a rejected frame yields out_len[i] = 0 and the call
+ * returns SKYHIP_E_FORMAT after decoding every good frame. */
+int  skyhip_decompress_device(skyhip_ctx* ctx, int n,
+                              const void* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                              void* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                              uint64_t* out_len, int32_t* status);
+int  skyhip_decompress_batch(skyhip_ctx* ctx, int n,
+                             const uint8_t* const* in, const size_t* in_len,
+                             uint8_t* const* out, const size_t* out_cap, size_t* out_len, int32_t* status);
+double skyhip_decompress_ms(skyhip_ctx* ctx, int reset);   /* accumulated device time of scan + decode kernels */
 
 /* CDC results of the LAST process_* call that had SKYHIP_F_CDC set (host copies).
  * n_cuts[i] cut END offsets for chunk i are written to cuts + cut_prefix[i] ... ; fps holds 16 bytes per

@@ -48,3 +48,13 @@ for _ in range(2):
     ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_MD5)
 t = ctx.timing()
 print(f"md5 alone {t.md5_ms/2:8.2f} ms ({n} chunks)", flush=True)
+# decompression of the frames produced above (device resident)
+ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
+flen, _ = ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
+d_back = torch.empty(n * cb, dtype=torch.uint8, device="cuda")
+ctx.decompress_device(d_out.data_ptr(), out_off, flen, d_back.data_ptr(), in_off, in_len)
+ctx.decompress_ms(reset=True)
+for _ in range(2):
+    ctx.decompress_device(d_out.data_ptr(), out_off, flen, d_back.data_ptr(), in_off, in_len)
+ms = ctx.decompress_ms() / 2
+print(f"decompress {ms:8.2f} ms -> {n*cb/(ms/1e3)/1e9:7.1f} GB/s of output; roundtrip ok = {bool(torch.equal(d_back, d_in))}", flush=True)

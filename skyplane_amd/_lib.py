@@ -12,7 +12,7 @@ LIB_PATH = Path(os.environ.get("SKYHIP_LIB_PATH", _CSRC / "libskyhip.so"))   # o
 EXPORTS = (
     "skyhip_abi_version", "skyhip_create", "skyhip_destroy", "skyhip_frame_bound", "skyhip_process_batch", "skyhip_process_device",
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
-    "skyhip_last_hip_error", "skyhip_debug_prof",
+    "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
 )
 
 
@@ -72,6 +72,12 @@ def load() -> C.CDLL:
     lib.skyhip_reset_timing.restype = None
     lib.skyhip_selftest.argtypes = [vp]
     lib.skyhip_selftest.restype = C.c_int
+    lib.skyhip_decompress_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.skyhip_decompress_device.restype = C.c_int
+    lib.skyhip_decompress_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.skyhip_decompress_batch.restype = C.c_int
+    lib.skyhip_decompress_ms.argtypes = [vp, C.c_int]
+    lib.skyhip_decompress_ms.restype = C.c_double
     lib.skyhip_debug_prof.argtypes = [vp, vp]
     lib.skyhip_debug_prof.restype = C.c_int
     lib.skyhip_strerror.argtypes = [C.c_int]

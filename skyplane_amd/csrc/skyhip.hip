@@ -16,6 +16,7 @@
 #include "lz4_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
+#include "lz4d_kernel.inc"
 #ifdef SKY_WITH_CDC
 #include "gear_kernel.inc"
 #endif
@@ -30,6 +31,8 @@ extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compres
 extern "C" __global__ void __launch_bounds__(64) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
+extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_lz4_decode(SkyLz4dRun r) { sky_lz4_decode_body(r); }
 #ifdef SKY_WITH_CDC
 extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) sky_gear_candidates(SkyGearArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -124,6 +127,7 @@ template <typename T> struct PinBuf {
 #ifdef SKY_WITH_CDC
 #include "cdc_host.inc"
 #endif
+#include "lz4d_host.inc"
 
 struct skyhip_ctx {
     int dev = 0;
@@ -147,6 +151,8 @@ struct skyhip_ctx {
 #ifdef SKY_WITH_CDC
     SkyCdcState cdc;   // CDC / dedup state
 #endif
+    SkyLz4dState dec;   // frame decompressor state
+    double dec_ms = 0;
     // timing
     std::vector<EvPair> ev_busy, ev_free;
     skyhip_timing tm;
@@ -214,6 +220,7 @@ const char* skyhip_strerror(int code) {
         case SKYHIP_E_CAP: return "output buffer smaller than skyhip_frame_bound / cut capacity";
         case SKYHIP_E_NODEVICE: return "no usable gfx950 device";
         case SKYHIP_E_TABLEFULL: return "dedup table full";
+        case SKYHIP_E_FORMAT: return "malformed or unsupported LZ4 frame";
         default: return "unknown skyhip error";
     }
 }
@@ -275,6 +282,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
     c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release();
     c->d_stage_in.release(); c->d_stage_out.release();
+    c->dec.release();
 #ifdef SKY_WITH_CDC
     sky_cdc_state_release(&c->cdc);
 #endif
@@ -455,6 +463,48 @@ int skyhip_process_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const s
 #endif
     }
     return SKYHIP_OK;
+}
+
+int skyhip_decompress_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
+                             const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !in_off || !in_len || !d_out || !out_off || !out_cap))) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    return sky_lz4d_run(&c->dec, c->s_lz4, n, d_in, in_off, in_len, d_out, out_off, out_cap, out_len, status, &c->dec_ms, c->hip_err, sizeof c->hip_err);
+}
+
+int skyhip_decompress_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
+                            size_t* out_len, int32_t* status) {
+    if (!c || n < 0) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    if (!in || !in_len || !out || !out_cap || !out_len) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<uint64_t> ioff(n), ilen(n), ooff(n), ocap(n), olen(n);
+    uint64_t itot = 0, otot = 0;
+    for (int i = 0; i < n; i++) {
+        if (in_len[i] && !in[i]) return SKYHIP_E_INVAL;
+        ioff[i] = itot; ilen[i] = in_len[i]; itot += (in_len[i] + 255) & ~(uint64_t)255;
+        ooff[i] = otot; ocap[i] = out_cap[i]; otot += (out_cap[i] + 255) & ~(uint64_t)255;
+    }
+    HIPCHK(c, c->dec.d_stage_in.ensure(itot + 256)); HIPCHK(c, c->dec.d_stage_out.ensure(otot + 256));
+    for (int i = 0; i < n; i++)
+        if (in_len[i]) HIPCHK(c, hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_lz4));
+    int rc = sky_lz4d_run(&c->dec, c->s_lz4, n, c->dec.d_stage_in.p, ioff.data(), ilen.data(), c->dec.d_stage_out.p, ooff.data(), ocap.data(), olen.data(),
+                          status, &c->dec_ms, c->hip_err, sizeof c->hip_err);
+    if (rc != SKYHIP_OK && rc != SKYHIP_E_FORMAT) return rc;
+    for (int i = 0; i < n; i++) {
+        out_len[i] = (size_t)olen[i];
+        if (olen[i]) HIPCHK(c, hipMemcpyAsync(out[i], c->dec.d_stage_out.p + ooff[i], olen[i], hipMemcpyDeviceToHost, c->s_lz4));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    return rc;
+}
+
+double skyhip_decompress_ms(skyhip_ctx* c, int reset) {
+    if (!c) return 0.0;
+    const double v = c->dec_ms;
+    if (reset) c->dec_ms = 0;
+    return v;
 }
 
 int skyhip_cdc_results(skyhip_ctx* c, int n, uint64_t* cut_prefix, uint32_t* cuts, size_t cuts_cap, uint8_t* fps, uint64_t* first_seen,

@@ -115,6 +115,41 @@ class SkyHipContext:
         self._check(rc)
         return out_len, md5
 
+    # -- decompression (destination gateway: lz4.frame.decompress at gateway_receiver.py:195-201) ----------
+    def decompress_batch(self, frames: Sequence, raw_lens: Sequence[int]):
+        """frames[i] decodes into at most raw_lens[i] bytes (WireProtocolHeader.raw_data_len). Returns list of bytes;
+        raises SkyHipError(-8) if any frame is malformed (like lz4.frame.decompress raising)."""
+        n = len(frames)
+        if n == 0:
+            return []
+        arrs = [np.frombuffer(f, np.uint8) if not isinstance(f, np.ndarray) else np.ascontiguousarray(f.reshape(-1).view(np.uint8)) for f in frames]
+        outs = [np.empty(max(int(r), 1), np.uint8) for r in raw_lens]
+        in_ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        in_len = (C.c_size_t * n)(*[a.size for a in arrs])
+        out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        out_cap = (C.c_size_t * n)(*[int(r) for r in raw_lens])
+        out_len = (C.c_size_t * n)()
+        status = (C.c_int32 * n)()
+        rc = self._lib.skyhip_decompress_batch(self._h, n, in_ptrs, in_len, out_ptrs, out_cap, out_len, status)
+        self.last_decode_status = list(status)
+        self._check(rc)
+        return [outs[i][: out_len[i]].tobytes() for i in range(n)]
+
+    def decompress_device(self, d_in: int, in_off, in_len, d_out: int, out_off, out_cap):
+        n = int(len(in_off))
+        in_off = np.ascontiguousarray(in_off, np.uint64); in_len = np.ascontiguousarray(in_len, np.uint64)
+        out_off = np.ascontiguousarray(out_off, np.uint64); out_cap = np.ascontiguousarray(out_cap, np.uint64)
+        out_len = np.zeros(n, np.uint64)
+        status = np.zeros(n, np.int32)
+        rc = self._lib.skyhip_decompress_device(self._h, n, C.c_void_p(d_in), in_off.ctypes.data, in_len.ctypes.data, C.c_void_p(d_out),
+                                                out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data)
+        self.last_decode_status = status.tolist()
+        self._check(rc)
+        return out_len
+
+    def decompress_ms(self, reset: bool = True) -> float:
+        return float(self._lib.skyhip_decompress_ms(self._h, int(reset)))
+
     def cdc_results(self, n: int, in_len: np.ndarray):
         """CDC output of the last call with F_CDC: (cut_prefix[n+1], cuts, fingerprints[nseg,16], first_seen[nseg], seg_base)."""
         cap = int(sum(int(l) // 4096 + 2 for l in in_len))

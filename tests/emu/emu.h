@@ -13,7 +13,7 @@
 #define SKY_WAVE 64
 typedef unsigned long long sky_u64;
 
-enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT };
+enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT, EMU_WAVESYNC };
 
 struct EmuLaneState {
     void* sp;            // saved stack pointer of the parked coroutine
@@ -50,7 +50,9 @@ SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV void sky_syncthreads() { emu_collective(EMU_BARRIER, 0, 0); }
-SKY_DEV void sky_wave_fence() {}
+// lanes of the emulator run one after the other between collectives; on hardware they run in lock-step, and the
+// kernels put a wave fence wherever a lane reads what another lane of the same wave just wrote: make it a rendezvous
+SKY_DEV void sky_wave_fence() { emu_collective(EMU_WAVESYNC, 0, 0); }
 
 // lanes never run concurrently, so plain read-modify-write is atomic here
 SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }

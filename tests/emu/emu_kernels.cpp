@@ -10,6 +10,7 @@
 #include "lz4_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
+#include "lz4d_kernel.inc"
 #ifdef SKY_WITH_CDC
 #include "gear_kernel.inc"
 #endif
@@ -66,6 +67,37 @@ uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_S
 }
 
 uint32_t emu_slot_bytes(void) { return SKY_LZ4_SLOT; }
+
+static void k_dscan(void* a, uint8_t*) { sky_lz4f_scan_body(*(SkyLz4dArgs*)a); }
+static void k_ddec(void* a, uint8_t*) { sky_lz4_decode_body(*(SkyLz4dRun*)a); }
+
+// mirrors sky_lz4d_run: scan, build work items, decode.  status[i] = decoder code, out_len[i] = decoded bytes.
+int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, int n, uint8_t* out, const uint64_t* out_off,
+                   const uint64_t* out_cap, uint64_t* out_len, int32_t* status) {
+    std::vector<sky_u64> ioff(in_off, in_off + n), ilen(in_len, in_len + n), ooff(out_off, out_off + n), ocap(out_cap, out_cap + n), content(n);
+    std::vector<uint32_t> prefix(n + 1), nblk(n), flags(n), bmax(n), err(n);
+    uint32_t slots = 0;
+    for (int i = 0; i < n; i++) { prefix[i] = slots; slots += (uint32_t)(ocap[i] / SKY_LZ4_BLOCK) + 2; }
+    prefix[n] = slots;
+    std::vector<sky_u64> bsrc(slots); std::vector<uint32_t> bword(slots), bframe(slots);
+    SkyLz4dArgs a; a.in = in; a.in_off = ioff.data(); a.in_len = ilen.data(); a.out = out; a.out_off = ooff.data(); a.out_cap = ocap.data();
+    a.blk_prefix = prefix.data(); a.n = (uint32_t)n; a.f_nblk = nblk.data(); a.f_flags = flags.data(); a.f_bmax = bmax.data(); a.f_content = content.data();
+    a.f_err = err.data(); a.b_src = bsrc.data(); a.b_word = bword.data(); a.b_frame = bframe.data(); a.n_slots = slots;
+    emu_launch((n + 63) / 64, 64, 0, k_dscan, &a);
+    std::vector<uint32_t> items;
+    for (int i = 0; i < n; i++) {
+        if (!nblk[i]) continue;
+        if (flags[i] & 1u) for (uint32_t b = 0; b < nblk[i]; b++) items.push_back(prefix[i] + b);
+        else items.push_back((uint32_t)i | 0x80000000u);
+    }
+    if (!items.empty()) {
+        SkyLz4dRun r; r.a = a; r.item_slot = items.data(); r.n_items = (uint32_t)items.size();
+        emu_launch(((int)items.size() + 3) / 4, 256, 0, k_ddec, &r);
+    }
+    int rc = 0;
+    for (int i = 0; i < n; i++) { status[i] = (int32_t)err[i]; out_len[i] = err[i] ? 0 : content[i]; if (err[i]) rc = -8; }
+    return rc;
+}
 
 #ifdef SKY_WITH_CDC
 static void k_gcand(void* a, uint8_t* smem) { sky_gear_candidates_body(*(SkyGearArgs*)a, smem); }

@@ -23,6 +23,8 @@ def lib() -> C.CDLL:
         l.emu_lz4_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.emu_lz4_block.restype = C.c_uint32
         l.emu_slot_bytes.restype = C.c_uint32
+        l.emu_decompress.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5
+        l.emu_decompress.restype = C.c_int
         l.emu_cdc.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
         l.emu_cdc.restype = C.c_long
         _lib = l
@@ -105,3 +107,34 @@ class EmuCdc:
         if dedup:
             self.seg_base += tot
         return prefix, seg_end[:tot], fps[:tot], (first[:tot] if dedup else None), base, cc[:ntiles]
+
+
+def decompress(frames, caps):
+    """frames: list[bytes]; caps: list[int] output capacities. Returns (rc, outputs list[bytes], status list[int])."""
+    n = len(frames)
+    in_len = np.array([len(f) for f in frames], np.uint64)
+    in_off = np.zeros(n, np.uint64)
+    pos = 5  # misaligned on purpose
+    for i, f in enumerate(frames):
+        in_off[i] = pos
+        pos += len(f) + 3
+    ibuf = np.full(pos + 64, 0x5A, np.uint8)
+    for i, f in enumerate(frames):
+        ibuf[int(in_off[i]):int(in_off[i]) + len(f)] = np.frombuffer(f, np.uint8)
+    out_off = np.zeros(n, np.uint64)
+    out_cap = np.array(caps, np.uint64)
+    pos = 7
+    for i in range(n):
+        out_off[i] = pos
+        pos += int(caps[i]) + 9
+    obuf = np.full(pos + 64, 0xEE, np.uint8)
+    out_len = np.zeros(n, np.uint64)
+    status = np.zeros(n, np.int32)
+    rc = lib().emu_decompress(ibuf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, n, obuf.ctypes.data, out_off.ctypes.data, out_cap.ctypes.data,
+                              out_len.ctypes.data, status.ctypes.data)
+    outs = [obuf[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
+    for i in range(n):   # nothing written past the capacity
+        end = int(out_off[i]) + int(caps[i])
+        nxt = int(out_off[i + 1]) if i + 1 < n else obuf.size
+        assert (obuf[end:nxt] == 0xEE).all(), f"frame {i}: wrote past its capacity"
+    return rc, outs, status.tolist()

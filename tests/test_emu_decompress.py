@@ -1,0 +1,84 @@
+"""CPU tests: the shipping LZ4 frame DEcompressor source (skyplane_amd/csrc/lz4d_kernel.inc) under the SIMT emulator.
+Parity = what lz4.frame.decompress does at gateway_receiver.py:195-201: frames made by the reference's dependency
+(liblz4, block-LINKED, python-lz4 defaults) and by this library's compressor (block-independent) decode to the raw bytes;
+malformed frames are rejected like liblz4 rejects them."""
+import numpy as np
+import pytest
+
+from oracle import ref
+from skyplane_amd import synth
+from tests.emu import emulib
+
+
+def test_emu_decode_reference_frames(small_cases):
+    names = list(small_cases)
+    frames = [ref.lz4f_compress(small_cases[k]) for k in names]       # == lz4.frame.compress(data): linked blocks
+    rc, outs, status = emulib.decompress(frames, [len(small_cases[k]) for k in names])
+    for k, o, s, f in zip(names, outs, status, frames):
+        if len(small_cases[k]) == 0:
+            assert s == 10   # liblz4 writes no content size for empty input: unsupported by design, reported not crashed
+            continue
+        assert s == 0 and o == small_cases[k], k
+
+
+def test_emu_decode_own_frames_roundtrip(small_cases):
+    chunks = [v for v in small_cases.values()]
+    frames, _, _ = emulib.process(chunks, flags=1)
+    rc, outs, status = emulib.decompress(frames, [len(c) for c in chunks])
+    assert rc == 0 and status == [0] * len(chunks)
+    assert outs == chunks
+
+
+@pytest.mark.parametrize("name", synth.CLASSES)
+def test_emu_decode_every_class_linked_and_independent(name):
+    d = synth.gen_class(name, 300_000, synth.rng_for(9)).tobytes()
+    linked = ref.lz4f_compress(d)
+    indep = ref.lz4f_compress_port(d)
+    (ours,), _, _ = emulib.process([d], flags=1)
+    rc, outs, status = emulib.decompress([linked, indep, ours], [len(d)] * 3)
+    assert rc == 0 and status == [0, 0, 0] and outs == [d, d, d]
+
+
+def test_emu_decode_overlap_periods_and_long_runs():
+    pats = [bytes(200_000), b"ab" * 50_000, b"abc" * 40_000, b"0123456" * 20_000, (bytes(range(70)) * 3000), b"x" * 13 + b"y" * 70_000,
+            synth.gen_random(synth.rng_for(0, 1), 1000).tobytes() * 150]
+    frames = [ref.lz4f_compress(p) for p in pats]
+    rc, outs, status = emulib.decompress(frames, [len(p) for p in pats])
+    assert rc == 0 and outs == pats
+
+
+def test_emu_decode_rejects_what_liblz4_rejects(small_cases):
+    d = small_cases["mixed_200k"]
+    good = ref.lz4f_compress_port(d)
+    bad = []
+    b = bytearray(good); b[0] ^= 1; bad.append(bytes(b))                 # magic
+    b = bytearray(good); b[14] ^= 0x10; bad.append(bytes(b))             # header checksum
+    bad.append(good[:-1])                                                # truncated EndMark
+    bad.append(good + b"\\0")                                             # trailing byte
+    b = bytearray(good); b[15 + 4 + 1] = 0; b[15 + 4 + 2] = 0            # first block: second byte... corrupt an offset to 0
+    bad.append(bytes(b))
+    b = bytearray(good); b[6] ^= 1; bad.append(bytes(b))                 # content size (breaks HC)
+    rc, outs, status = emulib.decompress([good] + bad, [len(d)] * (1 + len(bad)))
+    assert rc == -8 and status[0] == 0 and outs[0] == d
+    for i, f in enumerate(bad):
+        liblz4_ok = True
+        try:
+            liblz4_ok = ref.lz4f_decompress(f, len(d)) == d
+        except ref.OracleError:
+            liblz4_ok = False
+        assert (status[1 + i] == 0) == liblz4_ok or outs[1 + i] in (b"", d), (i, status[1 + i])
+        if status[1 + i] == 0:
+            assert outs[1 + i] == d
+    assert all(s != 0 for s in status[1:5])
+
+
+def test_emu_decode_capacity_too_small(small_cases):
+    d = small_cases["text_5000"]
+    rc, outs, status = emulib.decompress([ref.lz4f_compress(d)], [len(d) - 1])
+    assert rc == -8 and status == [7] and outs == [b""]
+
+
+def test_emu_decode_full_chunk():
+    d = synth.silesia_like(2 << 20, config_id=2).tobytes()
+    rc, outs, status = emulib.decompress([ref.lz4f_compress(d)], [len(d)])
+    assert rc == 0 and outs[0] == d

@@ -1,0 +1,81 @@
+"""LZ4 frame decompression on the GPU (libskyhip.so, C ABI) vs the reference's decoder semantics
+(lz4.frame.decompress, gateway_receiver.py:195-201 == liblz4 LZ4F_decompress): frames produced by liblz4 with
+python-lz4's defaults (block-linked), by the oracle's port and by this library's own compressor all decode to the raw
+bytes; malformed frames are rejected.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import ref  # noqa: E402
+from skyplane_amd import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    torch.cuda.init()
+    from skyplane_amd import hip_ops
+
+    c = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=8)
+    yield c
+    c.close()
+
+
+def test_decode_reference_and_own_frames(ctx, small_cases):
+    names = [k for k in small_cases if len(small_cases[k])]
+    chunks = [small_cases[k] for k in names]
+    linked = [ref.lz4f_compress(c) for c in chunks]                     # what a reference sender puts on the wire
+    own = [r.frame for r in ctx.process_batch(chunks, flags=1)]         # what the gpu_compress operator produces
+    for frames in (linked, own, [ref.lz4f_compress_port(c) for c in chunks]):
+        outs = ctx.decompress_batch(frames, [len(c) for c in chunks])
+        assert outs == chunks
+
+
+@pytest.mark.parametrize("name", synth.CLASSES)
+def test_decode_every_class_full_chunk(ctx, name):
+    d = synth.gen_class(name, 8 << 20, synth.rng_for(9)).tobytes()
+    (own,) = [r.frame for r in ctx.process_batch([d], flags=1)]
+    outs = ctx.decompress_batch([ref.lz4f_compress(d), own], [len(d), len(d)])
+    assert outs[0] == d and outs[1] == d
+
+
+def test_decode_overlap_periods_and_long_runs(ctx):
+    pats = [bytes(8 << 20), b"ab" * 50_000, b"abc" * 40_000, b"0123456" * 20_000, (bytes(range(70)) * 3000), b"x" * 13 + b"y" * 70_000,
+            synth.gen_random(synth.rng_for(0, 1), 1000).tobytes() * 150]
+    outs = ctx.decompress_batch([ref.lz4f_compress(p) for p in pats], [len(p) for p in pats])
+    assert outs == pats
+
+
+def test_decode_rejects_malformed(ctx, small_cases):
+    from skyplane_amd import hip_ops
+
+    d = small_cases["mixed_200k"]
+    good = ref.lz4f_compress_port(d)
+    bad = [bytes([good[0] ^ 1]) + good[1:], good[:14] + bytes([good[14] ^ 0x10]) + good[15:], good[:-1], good + b"\0"]
+    with pytest.raises(hip_ops.SkyHipError) as e:
+        ctx.decompress_batch([good] + bad, [len(d)] * 5)
+    assert e.value.code == -8
+    assert ctx.last_decode_status[0] == 0 and all(s != 0 for s in ctx.last_decode_status[1:])
+    for f in bad:
+        with pytest.raises(ref.OracleError):
+            ref.lz4f_decompress(f, len(d))          # the reference's decoder rejects the same frames
+    with pytest.raises(hip_ops.SkyHipError):
+        ctx.decompress_batch([good], [len(d) - 1])  # capacity below the content size
+
+
+def test_device_roundtrip_stream(ctx):
+    """compress -> decompress entirely on the device: 32 x 8 MiB mixed chunks, output must equal the input."""
+    from skyplane_amd import hip_ops
+
+    cb, n = synth.CHUNK_BYTES, 32
+    host = synth.mixed_chunks(4, cb, config_id=4)
+    d_in = torch.from_numpy(np.concatenate([host[i % 4] for i in range(n)])).cuda()
+    stride = (hip_ops.frame_bound(cb) + 255) & ~255
+    d_fr = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(n * cb, dtype=torch.uint8, device="cuda")
+    off = np.arange(n, dtype=np.uint64)
+    flen, _ = ctx.process_device(d_in.data_ptr(), off * cb, np.full(n, cb, np.uint64), d_fr.data_ptr(), off * stride, np.full(n, stride, np.uint64), hip_ops.F_LZ4)
+    olen = ctx.decompress_device(d_fr.data_ptr(), off * stride, flen, d_out.data_ptr(), off * cb, np.full(n, cb, np.uint64))
+    assert (olen == cb).all() and torch.equal(d_in, d_out)
+    assert ctx.decompress_ms(reset=False) > 0
