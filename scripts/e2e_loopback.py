@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Config-5 shape at reduced scale, with this repo's stand-alone mirrors of the gateway pieces (the reference daemon
+itself cannot be imported offline):
+
+    chunk files -> gpu_compress operator (forked worker, GPU) -> sender threads (sidecar frames, 53-byte headers)
+                -> loopback TCP, K connections -> receiver process (GPU decompress) -> chunk files
+
+Reports effective Gbit/s = raw bytes x 8 / wall time and verifies every destination file against its source.
+Plumbing (Python, tmpfs files, pickled queues, per-batch MD5 latency) bounds this number, not the kernels.
+"""
+import argparse
+import hashlib
+import json
+import os
+import queue as pyqueue
+import socket
+import sys
+import tempfile
+import threading
+import time
+import uuid
+from multiprocessing import Event, Process, Queue
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from skyplane_amd import synth  # noqa: E402
+from skyplane_amd.chunk import Chunk, ChunkRequest  # noqa: E402
+from skyplane_amd.gateway.chunk_store import ChunkStore  # noqa: E402
+from skyplane_amd.gateway.gateway_queue import GatewayQueue  # noqa: E402
+from skyplane_amd.gateway.operators import hip_receiver, hip_sender  # noqa: E402
+from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress  # noqa: E402
+
+
+def receiver_main(dst_dir, port_q, done_q, n_conn, max_chunk):
+    """Destination gateway stand-in: one process, one thread per connection, one HIP context (created here, after fork)."""
+    from skyplane_amd import hip_ops
+
+    store = ChunkStore(dst_dir)
+    ctx = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=max_chunk, max_batch=4)
+    lock = threading.Lock()
+
+    def decompress(frame, raw_len):
+        with lock:
+            return ctx.decompress_batch([frame], [raw_len])[0]
+
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(n_conn)
+    port_q.put(srv.getsockname()[1])
+
+    def serve(conn):
+        with conn:
+            done_q.put(hip_receiver.recv_chunks(conn, store, decompress))
+
+    threads = []
+    for _ in range(n_conn):
+        conn, _ = srv.accept()
+        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        t = threading.Thread(target=serve, args=(conn,))
+        t.start()
+        threads.append(t)
+    for t in threads:
+        t.join()
+    ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=64)
+    ap.add_argument("--chunk-mib", type=int, default=8)
+    ap.add_argument("--connections", type=int, default=4)
+    ap.add_argument("--max-batch", type=int, default=32)
+    args = ap.parse_args()
+    size = args.chunk_mib << 20
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        src, dst = ChunkStore(Path(tmp) / "src"), Path(tmp) / "dst"
+        q_in, q_out = GatewayQueue(), GatewayQueue()
+        src.add_partition("0", q_in)
+        base = synth.mixed_chunks(4, size, config_id=4)
+        reqs, digests = [], {}
+        for i in range(args.chunks):
+            cid = uuid.uuid4().hex
+            data = base[i % 4].tobytes()
+            src.get_chunk_file_path(cid).write_bytes(data)
+            digests[cid] = hashlib.md5(data).digest()
+            reqs.append(ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0")))
+        port_q, done_q = Queue(), Queue()
+        rx = Process(target=receiver_main, args=(dst, port_q, done_q, args.connections, size))
+        rx.start()
+        port = port_q.get(timeout=120)
+        err_ev, err_q = Event(), Queue()
+        op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=1, max_batch=args.max_batch, max_chunk_bytes=size, device_ids=[0])
+        # static split of the chunk set over the connections, like the reference's per-connection chunk lists
+        shares = [reqs[k::args.connections] for k in range(args.connections)]
+        ready = {}            # chunk_id -> ChunkRequest once the operator has produced its sidecar
+        ready_cv = threading.Condition()
+
+        def collect():
+            got = 0
+            while got < len(reqs) and not err_ev.is_set():
+                try:
+                    cr = q_out.q.get(timeout=0.2)
+                except pyqueue.Empty:
+                    continue
+                with ready_cv:
+                    ready[cr.chunk.chunk_id] = cr
+                    ready_cv.notify_all()
+                got += 1
+
+        wire = [0] * args.connections
+
+        def send(k):
+            with socket.create_connection(("127.0.0.1", port)) as sock:
+                sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                for idx, cr in enumerate(shares[k]):
+                    with ready_cv:
+                        ready_cv.wait_for(lambda: cr.chunk.chunk_id in ready or err_ev.is_set(), timeout=300)
+                    header, payload = hip_sender.wire_payload(src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
+                    header.to_socket(sock)
+                    sock.sendall(payload)
+                    wire[k] += len(payload)
+
+        t0 = time.perf_counter()
+        for cr in reqs:
+            src.add_chunk_request(cr)
+        op.start_workers()
+        threads = [threading.Thread(target=collect)] + [threading.Thread(target=send, args=(k,)) for k in range(args.connections) if shares[k]]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        n_rx = 0
+        for _ in range(sum(1 for s in shares if s)):
+            n_rx += len(done_q.get(timeout=300))
+        elapsed = time.perf_counter() - t0
+        op.stop_workers()
+        rx.join(60)
+        assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
+        assert n_rx == len(reqs)
+        for cr in reqs:
+            got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
+            assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+        raw = len(reqs) * size
+        print(json.dumps({"e2e": "loopback", "chunks": len(reqs), "chunk_mib": args.chunk_mib, "connections": args.connections,
+                          "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 2), "raw_GiB": round(raw / 2**30, 2), "wire_ratio": round(raw / sum(wire), 3),
+                          "seconds": round(elapsed, 2), "verified": True}))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,18 @@ def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left
     return header, data
 
 
+def send_chunks(sock, chunk_store: ChunkStore, chunk_reqs) -> int:
+    """The per-connection send loop of GatewaySender.process (gateway_operator.py:343-402) minus its HTTP
+    pre-registration and retry-on-reconnect: header, then payload, for every chunk; returns wire bytes sent."""
+    sent = 0
+    for idx, chunk_req in enumerate(chunk_reqs):
+        header, payload = wire_payload(chunk_store, chunk_req, n_chunks_left_on_socket=len(chunk_reqs) - idx - 1)
+        header.to_socket(sock)
+        sock.sendall(payload)
+        sent += len(payload)
+    return sent
+
+
 def chunk_digest(chunk_store: ChunkStore, chunk_id: str) -> Optional[bytes]:
     """The 16-byte digest Chunk.md5_hash is declared to carry (chunk.py:21), read from the side channel."""
     p = chunk_store.get_digest_file_path(chunk_id)

@@ -15,3 +15,10 @@ def test_operator_end_to_end():
     script = Path(__file__).resolve().parent / "_operator_e2e.py"
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=400)
     assert p.returncode == 0 and "operator e2e ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_loopback_sender_receiver_end_to_end():
+    """operator -> sender -> loopback TCP -> receiver (GPU decompress) -> files; every destination file verified."""
+    script = Path(__file__).resolve().parents[1] / "scripts" / "e2e_loopback.py"
+    p = subprocess.run([sys.executable, str(script), "--chunks", "16", "--connections", "2", "--max-batch", "8"], capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0 and '"verified": true' in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
