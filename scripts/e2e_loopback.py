@@ -112,6 +112,17 @@ def main():
                 got += 1
 
         wire = [0] * args.connections
+        status_records = []
+        stop_drain = threading.Event()
+
+        def drain_status():
+            # the daemon's main loop does this (gateway_daemon.py:329-330); an undrained multiprocessing queue would
+            # keep the operator's worker process from exiting
+            while not stop_drain.is_set() or not src.chunk_status_queue.empty():
+                try:
+                    status_records.append(src.chunk_status_queue.get(timeout=0.1))
+                except pyqueue.Empty:
+                    pass
 
         def send(k):
             with socket.create_connection(("127.0.0.1", port)) as sock:
@@ -128,6 +139,8 @@ def main():
         for cr in reqs:
             src.add_chunk_request(cr)
         op.start_workers()
+        drainer = threading.Thread(target=drain_status)
+        drainer.start()
         threads = [threading.Thread(target=collect)] + [threading.Thread(target=send, args=(k,)) for k in range(args.connections) if shares[k]]
         for t in threads:
             t.start()
@@ -137,7 +150,9 @@ def main():
         for _ in range(sum(1 for s in shares if s)):
             n_rx += len(done_q.get(timeout=300))
         elapsed = time.perf_counter() - t0
+        stop_drain.set()
         op.stop_workers()
+        drainer.join()
         rx.join(60)
         assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
         assert n_rx == len(reqs)
@@ -147,7 +162,7 @@ def main():
         raw = len(reqs) * size
         print(json.dumps({"e2e": "loopback", "chunks": len(reqs), "chunk_mib": args.chunk_mib, "connections": args.connections,
                           "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 2), "raw_GiB": round(raw / 2**30, 2), "wire_ratio": round(raw / sum(wire), 3),
-                          "seconds": round(elapsed, 2), "verified": True}))
+                          "seconds": round(elapsed, 2), "status_records": len(status_records), "verified": True}))
 
 
 if __name__ == "__main__":
