@@ -32,7 +32,7 @@ class GatewayOperator:
 
 
 class GatewayGpuCompress(GatewayOperator):
-    def __init__(self, num_workers: int = 1, max_batch: int = 8, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False):
+    def __init__(self, num_workers: int = 1, max_batch: int = 32, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False):
         super().__init__("gpu_compress")
         self.num_workers = num_workers      # one forked worker per GPU is the intended setting
         self.max_batch = max_batch
@@ -49,6 +49,6 @@ def create_operator(op: dict, handle: str, region: str, input_queue, output_queu
     if op["op_type"] != "gpu_compress":
         raise ValueError(f"Unsupported op_type {op['op_type']}")   # same failure mode as gateway_daemon.py:267-268
     return GatewayHipCompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
-                              error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 8),
+                              error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 32),
                               max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, compute_md5=op.get("compute_md5", True), cdc=op.get("cdc", False),
                               dedup=op.get("dedup", False))

@@ -124,12 +124,14 @@ class GatewayHipCompress(GatewayOperator):
                           json.dumps at :299)
     and reports ``compressed_size_bytes`` / ``uncompressed_size_bytes`` in the status metadata consumed by the
     reference's compression profile endpoint (gateway_daemon_api.py:129-134, :340-354).
+    ``max_batch`` should be large: whole-chunk MD5 is a serial chain (about 0.1 s per 8 MiB on one GPU lane whatever the
+    batch size), so a worker moves at most max_batch x chunk / chain-time; LZ4 for the same batch takes milliseconds.
     Worker i binds GPU ``device_ids[i % len(device_ids)]``: chunks are independent, so the N GPUs of a node are N
     workers pulling from one queue -- no collective anywhere.
     """
 
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
-                 chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 8, max_chunk_bytes: int = 64 << 20,
+                 chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
