@@ -198,7 +198,9 @@ def main():
             res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
             res["roofline"]["traffic_source"] = t["source"]
         if args.cdc:
-            res["config"]["workload"] = res["config"]["workload"].replace("configs[1]", "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table; 50 %-duplicate stream)")
+            res["config"]["workload"] = (res["config"]["workload"].replace("configs[1]", "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table)")
+                                         .replace("Silesia-like synthetic stream", "synthetic stream with ~50 % of its 8-64 KiB spans copied from earlier spans at unaligned offsets")
+                                         .replace("tiled+rotated; no Silesia corpus offline", "tiled, rotated and XOR-ed per tile so that tiles are mutually distinct"))
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
             prefix, cuts, fps, first, base = ctx.cdc_results(n_chunks, in_len)
             import numpy as _np
