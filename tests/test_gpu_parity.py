@@ -211,3 +211,34 @@ def test_cdc_device_path_config3_stream(ctx):
     seg_len = np.where(seg_len > 0, seg_len, np.concatenate(ecuts))  # first segment of each chunk
     dup_bytes = int(seg_len[first != np.arange(len(first))].sum())
     assert dup_bytes > 0
+
+
+def test_reference_default_chunk_size_64MiB_unaligned_device_offsets():
+    """The reference's default multipart chunk is 64 MiB (skyplane/api/config.py:117).  One such chunk plus a short one,
+    placed at odd byte offsets in the device buffers, through LZ4 + MD5 + CDC."""
+    from skyplane_amd import hip_ops
+
+    big = np.concatenate([synth.silesia_like(32 << 20, config_id=2), synth.mixed_chunks(4, 8 << 20, config_id=4).reshape(-1)])
+    small = synth.gen_text(synth.rng_for(1), 12345)
+    assert big.size == 64 << 20
+    with hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=64 << 20, max_batch=2) as c:
+        d_in = torch.zeros(big.size + small.size + 64, dtype=torch.uint8, device="cuda")
+        in_off = np.array([3, 3 + big.size + 7], np.uint64)
+        in_len = np.array([big.size, small.size], np.uint64)
+        d_in[3:3 + big.size] = torch.from_numpy(big).cuda()
+        d_in[int(in_off[1]):int(in_off[1]) + small.size] = torch.from_numpy(small).cuda()
+        caps = np.array([hip_ops.frame_bound(big.size), hip_ops.frame_bound(small.size)], np.uint64)
+        out_off = np.array([5, 5 + int(caps[0]) + 11], np.uint64)
+        d_out = torch.zeros(int(out_off[1] + caps[1]) + 64, dtype=torch.uint8, device="cuda")
+        out_len, md5 = c.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, caps, hip_ops.F_LZ4 | hip_ops.F_MD5 | hip_ops.F_CDC)
+        frames = d_out.cpu().numpy()
+        prefix, cuts, fps, first, base = c.cdc_results(2, in_len)
+        for i, raw in enumerate((big, small)):
+            assert md5[i].tobytes() == hashlib.md5(raw).digest()
+            f = frames[int(out_off[i]):int(out_off[i]) + int(out_len[i])]
+            assert ref.lz4f_decompress(f, raw.size) == raw.tobytes()
+            assert (cuts[int(prefix[i]):int(prefix[i + 1])] == ref.gear_cdc(raw)).all()
+        # and back through the GPU decompressor at odd offsets
+        d_back = torch.zeros(big.size + small.size + 64, dtype=torch.uint8, device="cuda")
+        olen = c.decompress_device(d_out.data_ptr(), out_off, out_len, d_back.data_ptr(), in_off, in_len)
+        assert (olen == in_len).all() and torch.equal(d_back[3:3 + big.size].cpu(), torch.from_numpy(big))
