@@ -112,7 +112,9 @@ int  skyhip_decompress_batch(skyhip_ctx* ctx, int n,
                              uint8_t* const* out, const size_t* out_cap, size_t* out_len, int32_t* status);
 double skyhip_decompress_ms(skyhip_ctx* ctx, int reset);   /* accumulated device time of scan + decode kernels */
 
-/* CDC results of the LAST process_* call that had SKYHIP_F_CDC set (host copies).
+/* CDC results of the LAST device launch that had SKYHIP_F_CDC set (host copies).  skyhip_process_batch splits a batch
+ * larger than max_batch into sub-batches; it fills its own cuts[]/n_cuts[] for every chunk, but this call then
+ * describes the last sub-batch only -- use batches <= max_batch (or skyhip_process_device) when fingerprints are needed.
  * n_cuts[i] cut END offsets for chunk i are written to cuts + cut_prefix[i] ... ; fps holds 16 bytes per
  * segment in the same order; first_seen[k] = global index of the first segment with that fingerprint
  * (== its own global index when it is not a duplicate).  Any pointer may be NULL. */

@@ -287,6 +287,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     sky_cdc_state_release(&c->cdc);
 #endif
     if (c->d_self) (void)hipFree(c->d_self);
+    if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->s_lz4) (void)hipStreamDestroy(c->s_lz4);
     if (c->s_md5) (void)hipStreamDestroy(c->s_md5);
     if (c->s_cdc) (void)hipStreamDestroy(c->s_cdc);
