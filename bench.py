@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--unit-mib", type=int, default=256)
     ap.add_argument("--max-batch", type=int, default=2048, help="chunks per LZ4 sub-batch (scratch = 8.06 MiB each; fewer, larger launches = fewer launch tails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream", choices=["silesia", "mixed"], default="silesia",
+                    help="silesia = configs[1] stand-in (default); mixed = configs[3] stream: every chunk one of {random, text, records+binary, sparse}")
     ap.add_argument("--cdc", action="store_true", help="configs[2]: add Gear CDC + segment fingerprints + dedup table on a 50 %%-duplicate stream")
     args = ap.parse_args()
 
@@ -110,7 +112,12 @@ def main():
 
     # ---- synthetic stream: unit generated on the host (deterministic), tiled + rotated on the device ----
     t0 = time.perf_counter()
-    unit = synth.dedup_stream(unit_bytes, dup_fraction=0.5, config_id=3) if args.cdc else synth.silesia_like(unit_bytes, config_id=2)
+    if args.cdc:
+        unit = synth.dedup_stream(unit_bytes, dup_fraction=0.5, config_id=3)
+    elif args.stream == "mixed":
+        unit = synth.mixed_chunks(unit_bytes // cb, cb, config_id=4).reshape(-1)
+    else:
+        unit = synth.silesia_like(unit_bytes, config_id=2)
     d_unit = torch.from_numpy(unit).to(dev)
     d_in = torch.empty(n_chunks * cb, dtype=torch.uint8, device=dev)
     per = unit_bytes // cb
@@ -197,6 +204,9 @@ def main():
             per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
             res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
             res["roofline"]["traffic_source"] = t["source"]
+        if args.stream == "mixed" and not args.cdc:
+            res["config"]["workload"] = (res["config"]["workload"].replace("configs[1]", "configs[3] stream on one GPU")
+                                         .replace("Silesia-like synthetic stream", "mixed-compressibility stream (per chunk one of random / text / records+binary / sparse)"))
         if args.cdc:
             res["config"]["workload"] = (res["config"]["workload"].replace("configs[1]", "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table)")
                                          .replace("Silesia-like synthetic stream", "synthetic stream with ~50 % of its 8-64 KiB spans copied from earlier spans at unaligned offsets")
