@@ -98,9 +98,10 @@ int  skyhip_process_device(skyhip_ctx* ctx, int n,
 
 /* LZ4 frame DEcompression -- the destination gateway's mirrored hot loop:
  *   `data_batch_decompressed = lz4.frame.decompress(to_write)`   skyplane/gateway/operators/gateway_receiver.py:195-201
- * Accepts frames with a content size and 64 KiB..4 MiB blocks, block-independent (this library's) or block-linked
- * (python-lz4's default), stored blocks allowed, no checksums/dictionary.  out_len[i] = decoded bytes (== the frame's
- * content size, which the caller compares with WireProtocolHeader.raw_data_len as gateway_receiver.py:213-218 does).
+ * Accepts frames with 64 KiB..4 MiB blocks, block-independent (this library's) or block-linked (python-lz4's
+ * default), stored blocks allowed, content size present or absent, no checksums/dictionary.  out_len[i] = decoded
+ * bytes (== the frame's content size when it has one), which the caller compares with
+ * WireProtocolHeader.raw_data_len as gateway_receiver.py:213-218 does.
  * status[i] (may be NULL) = 0 or a positive decoder code; a rejected frame yields out_len[i] = 0 and the call
  * returns SKYHIP_E_FORMAT after decoding every good frame. */
 int  skyhip_decompress_device(skyhip_ctx* ctx, int n,

@@ -212,12 +212,16 @@ def liblz4_version() -> str:
     return liblz4().LZ4_versionString().decode()
 
 
-def lz4f_compress(data) -> bytes:
-    """== lz4.frame.compress(data) as called at gateway_operator.py:359 (python-lz4 defaults)."""
+def lz4f_compress(data, store_size: bool = True, block_linked: bool = True, block_size_id: int = 0) -> bytes:
+    """== lz4.frame.compress(data) as called at gateway_operator.py:359 (python-lz4 defaults).  The keyword
+    arguments produce the other frame flavours a receiver may meet (python-lz4's store_size / block_linked /
+    block_size knobs): no content size, independent blocks, 256 KiB..4 MiB blocks (ids 5..7)."""
     a = _buf(data)
     lib = liblz4()
     prefs = _Prefs()
-    prefs.frameInfo.contentSize = a.size  # python-lz4 store_size=True
+    prefs.frameInfo.contentSize = a.size if store_size else 0  # python-lz4 store_size=True
+    prefs.frameInfo.blockMode = 0 if block_linked else 1
+    prefs.frameInfo.blockSizeID = block_size_id
     bound = lib.LZ4F_compressFrameBound(a.size, C.byref(prefs))
     out = np.empty(bound, np.uint8)
     n = lib.LZ4F_compressFrame(out.ctypes.data, bound, a.ctypes.data, a.size, C.byref(prefs))

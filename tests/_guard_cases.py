@@ -1,0 +1,104 @@
+"""Run the shipping kernels (under the CPU SIMT emulator) on buffers fenced by inaccessible pages.
+
+Executed by tests/test_emu_guard.py in a child interpreter: an out-of-bounds access ends this process with SIGSEGV,
+which the parent reports as a failing test instead of taking pytest down with it.  TEST INFRASTRUCTURE ONLY.
+
+usage: python tests/_guard_cases.py {lz4|cdc|lz4d}
+"""
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref  # noqa: E402
+from tests.emu import emulib  # noqa: E402
+
+BLK = 65536
+
+
+def patterns(n: int, seed: int):
+    rng = np.random.default_rng(seed)
+    yield "zeros", bytes(n)
+    yield "random", rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    yield "period4", (b"\x01\x02\x03\x04" * (n // 4 + 1))[:n]
+    yield "period3", (b"abc" * (n // 3 + 1))[:n]
+    words = [b"gateway ", b"chunk ", b"region ", b"object ", b"transfer ", b"0123456789 "]
+    text = b"".join(words[int(i)] for i in rng.integers(0, len(words), n // 5 + 2))[:n]
+    yield "text", text
+    # zeros with a sprinkle of noise, ending in a long zero run (the shape that exposed the over-read)
+    sp = np.zeros(n, np.uint8)
+    if n > 64:
+        idx = rng.integers(0, n - 40, max(1, n // 97))
+        sp[idx] = rng.integers(1, 256, idx.size, dtype=np.uint8)
+    yield "sparse", sp.tobytes()
+
+
+def sizes_lz4():
+    s = set(range(0, 41))
+    for c in (64, 255, 256, 257, 270, 1024, 4096, BLK - 1, BLK, BLK + 1, BLK + 12, BLK + 13, BLK + 17, BLK + 21, BLK + 37, 2 * BLK):
+        s.add(c)
+    return sorted(s)
+
+
+def run_lz4():
+    for n in sizes_lz4():
+        for name, data in patterns(n, n + 7):
+            if n >= BLK - 1 and name in ("period3",):
+                continue
+            for guard in ("end", "start"):
+                frames, md5s, _ = emulib.process([data], flags=3, guard=guard)
+                assert ref.lz4f_decompress(frames[0], n) == data, (n, name, guard)
+                assert md5s[0] == hashlib.md5(data).digest(), (n, name, guard)
+    # a ragged batch: the fences are at the outer ends, chunk boundaries inside are checked by content
+    batch = [bytes(70000), b"x" * 13, b"", bytes(BLK)]
+    for guard in ("end", "start"):
+        frames, md5s, _ = emulib.process(batch, flags=3, guard=guard)
+        for f, m, d in zip(frames, md5s, batch):
+            assert ref.lz4f_decompress(f, len(d)) == d and m == hashlib.md5(d).digest()
+    print("OK lz4")
+
+
+def run_cdc():
+    gear = ref.gear_table()
+    for n in (1, 63, 64, 65, 4095, 4096, 4097, 32767, 32768, 32769, 100000, 3 * 65536):
+        for name, data in patterns(n, n + 11):
+            if name in ("period3", "period4"):
+                continue
+            want = [int(x) for x in ref.gear_cdc(data)]
+            for guard in ("end", "start"):
+                e = emulib.EmuCdc()
+                prefix, seg_end, fps, first, base, _ = e.run([data], gear, dedup=True, guard=guard)
+                got = [int(x) for x in seg_end[: int(prefix[1])]]
+                assert got == list(want), (n, name, guard)
+                lo = 0
+                for k, hi in enumerate(got):
+                    assert fps[k].tobytes() == hashlib.md5(data[lo:hi]).digest(), (n, name, guard, k)
+                    lo = hi
+    print("OK cdc")
+
+
+def run_lz4d():
+    for n in (0, 1, 12, 13, 40, 255, 4096, BLK - 1, BLK, BLK + 1, BLK + 21, 2 * BLK + 5):
+        for name, data in patterns(n, n + 3):
+            if n >= BLK - 1 and name in ("period3",):
+                continue
+            for linked in (False, True):
+                frame = ref.lz4f_compress(data) if linked else ref.lz4f_compress_port(data)
+                for guard in ("end", "start"):
+                    rc, outs, status = emulib.decompress([frame], [n], guard=guard)
+                    assert rc == 0 and status == [0] and outs[0] == data, (n, name, linked, guard, rc, status)
+    # frames produced by the GPU compressor's own source
+    for n in (BLK, BLK + 21):
+        for name, data in patterns(n, n + 5):
+            frame = emulib.process([data], flags=1)[0][0]
+            rc, outs, status = emulib.decompress([frame], [n], guard="end")
+            assert rc == 0 and outs[0] == data, (n, name)
+    print("OK lz4d")
+
+
+if __name__ == "__main__":
+    {"lz4": run_lz4, "cdc": run_cdc, "lz4d": run_lz4d}[sys.argv[1]]()

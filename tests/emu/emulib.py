@@ -3,6 +3,7 @@ emulator.  TEST INFRASTRUCTURE ONLY -- lets `-m "not gpu"` tests execute the ker
 from __future__ import annotations
 
 import ctypes as C
+import mmap
 import subprocess
 from pathlib import Path
 
@@ -31,33 +32,79 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_PAGE = mmap.PAGESIZE
+_libc = C.CDLL(None, use_errno=True)
+
+
+class Guarded:
+    """n bytes with an inaccessible page right after them (tight="end") or right before them (tight="start"):
+    a kernel that touches one byte outside its buffer takes SIGSEGV instead of silently reading a neighbour.
+    (That is how a 16-byte over-read at the very end of a 64 GiB device buffer was reproduced on the CPU.)"""
+
+    def __init__(self, n: int, tight: str = "end", fill: int = 0):
+        npages = max(1, (n + _PAGE - 1) // _PAGE)
+        self._mm = mmap.mmap(-1, (npages + 2) * _PAGE)
+        self._all = np.frombuffer(self._mm, np.uint8)
+        base = self._all.ctypes.data
+        assert base % _PAGE == 0
+        lo = _PAGE + (npages * _PAGE - n if tight == "end" else 0)
+        self.view = self._all[lo:lo + n]
+        self._all[_PAGE:_PAGE + npages * _PAGE] = fill
+        self.addr = base + lo
+        for a in (base, base + (npages + 1) * _PAGE):
+            if _libc.mprotect(C.c_void_p(a), C.c_size_t(_PAGE), 0) != 0:
+                raise OSError(C.get_errno(), "mprotect")
+
+
 def frame_bound(n: int) -> int:
     return 15 + n + 4 * ((n + 65535) // 65536) + 4
 
 
-def process(chunks, flags=3, blk_skew=0):
-    """chunks: list of bytes. Returns (frames: list[bytes], md5s: list[bytes], csizes)."""
+def _pack_inputs(chunks, guard):
+    """Lay the chunks out back to back (64-byte aligned starts).  guard=None: slack after the last chunk;
+    "end"/"start": the packed buffer sits flush against an inaccessible page on that side."""
     n = len(chunks)
-    lens = np.array([len(c) for c in chunks], np.uint64)
     in_off = np.zeros(n, np.uint64)
     pos = 0
+    end = 0
     for i, c in enumerate(chunks):
         in_off[i] = pos
+        end = pos + len(c)
         pos += (len(c) + 63) & ~63
-    buf = np.zeros(max(pos, 64) + 64, np.uint8)
+    if guard is None:
+        buf = np.zeros(max(pos, 64) + 64, np.uint8)
+        addr, keep = buf.ctypes.data, buf
+    else:
+        keep = Guarded(end, guard)
+        buf, addr = keep.view, keep.addr
     for i, c in enumerate(chunks):
         buf[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+    return in_off, addr, keep
+
+
+def process(chunks, flags=3, blk_skew=0, guard=None):
+    """chunks: list of bytes. Returns (frames: list[bytes], md5s: list[bytes], csizes).
+    guard: None | "end" | "start" -- see Guarded; input AND output buffers are then exactly as large as the C ABI
+    promises (sum of chunk bytes / frame bounds) and fenced by inaccessible pages."""
+    n = len(chunks)
+    lens = np.array([len(c) for c in chunks], np.uint64)
+    in_off, in_addr, _keep_in = _pack_inputs(chunks, guard)
     out_off = np.zeros(n, np.uint64)
-    pos = 3  # deliberately misaligned frame starts
+    pos = 3 if guard is None else 0  # deliberately misaligned frame starts
     for i, c in enumerate(chunks):
         out_off[i] = pos
-        pos += frame_bound(len(c)) + 5
-    out = np.full(pos + 64, 0xEE, np.uint8)
+        pos += frame_bound(len(c)) + (5 if i + 1 < n or guard is None else 0)
+    if guard is None:
+        out = np.full(pos + 64, 0xEE, np.uint8)
+        out_addr = out.ctypes.data
+    else:
+        _keep_out = Guarded(pos, guard, fill=0xEE)
+        out, out_addr = _keep_out.view, _keep_out.addr
     flen = np.zeros(n, np.uint64)
     md5 = np.zeros((n, 16), np.uint8)
     nb = int(sum((len(c) + 65535) // 65536 for c in chunks))
     cs = np.zeros(max(nb, 1), np.uint32)
-    rc = lib().emu_process(buf.ctypes.data, in_off.ctypes.data, lens.ctypes.data, n, out.ctypes.data, out_off.ctypes.data, flen.ctypes.data,
+    rc = lib().emu_process(in_addr, in_off.ctypes.data, lens.ctypes.data, n, out_addr, out_off.ctypes.data, flen.ctypes.data,
                            md5.ctypes.data, flags, blk_skew, cs.ctypes.data)
     assert rc == 0
     frames = [out[int(out_off[i]):int(out_off[i]) + int(flen[i])].tobytes() for i in range(n)]
@@ -80,17 +127,10 @@ class EmuCdc:
         self.first = np.full(1 << slots_log2, 0xFFFFFFFFFFFFFFFF, np.uint64)
         self.seg_base = 0
 
-    def run(self, chunks, gear, dedup=True):
+    def run(self, chunks, gear, dedup=True, guard=None):
         n = len(chunks)
         lens = np.array([len(c) for c in chunks], np.uint64)
-        in_off = np.zeros(n, np.uint64)
-        pos = 0
-        for i, c in enumerate(chunks):
-            in_off[i] = pos
-            pos += (len(c) + 63) & ~63
-        buf = np.zeros(max(pos, 64) + 64, np.uint8)
-        for i, c in enumerate(chunks):
-            buf[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+        in_off, in_addr, _keep_in = _pack_inputs(chunks, guard)
         cap = int(sum(len(c) // 4096 + 2 for c in chunks))
         prefix = np.zeros(n + 1, np.uint32)
         seg_end = np.zeros(cap, np.uint32)
@@ -99,7 +139,7 @@ class EmuCdc:
         ntiles = int(sum((len(c) + 32767) // 32768 for c in chunks))
         cc = np.zeros(max(ntiles, 1), np.uint32)
         gear = np.ascontiguousarray(gear, np.uint64)
-        tot = lib().emu_cdc(buf.ctypes.data, in_off.ctypes.data, lens.ctypes.data, n, gear.ctypes.data, prefix.ctypes.data, seg_end.ctypes.data, cap,
+        tot = lib().emu_cdc(in_addr, in_off.ctypes.data, lens.ctypes.data, n, gear.ctypes.data, prefix.ctypes.data, seg_end.ctypes.data, cap,
                             fps.ctypes.data, first.ctypes.data, self.key_lo.ctypes.data, self.key_hi.ctypes.data, self.first.ctypes.data,
                             self.slots_log2, self.seg_base, int(dedup), cc.ctypes.data)
         assert tot >= 0, tot
@@ -109,28 +149,43 @@ class EmuCdc:
         return prefix, seg_end[:tot], fps[:tot], (first[:tot] if dedup else None), base, cc[:ntiles]
 
 
-def decompress(frames, caps):
-    """frames: list[bytes]; caps: list[int] output capacities. Returns (rc, outputs list[bytes], status list[int])."""
+def decompress(frames, caps, guard=None):
+    """frames: list[bytes]; caps: list[int] output capacities. Returns (rc, outputs list[bytes], status list[int]).
+    guard: as in process()."""
     n = len(frames)
     in_len = np.array([len(f) for f in frames], np.uint64)
     in_off = np.zeros(n, np.uint64)
-    pos = 5  # misaligned on purpose
+    pos = 5 if guard is None else 0  # misaligned on purpose
+    end = 0
     for i, f in enumerate(frames):
         in_off[i] = pos
+        end = pos + len(f)
         pos += len(f) + 3
-    ibuf = np.full(pos + 64, 0x5A, np.uint8)
+    if guard is None:
+        ibuf = np.full(pos + 64, 0x5A, np.uint8)
+        iaddr = ibuf.ctypes.data
+    else:
+        _keep_in = Guarded(end, guard, fill=0x5A)
+        ibuf, iaddr = _keep_in.view, _keep_in.addr
     for i, f in enumerate(frames):
         ibuf[int(in_off[i]):int(in_off[i]) + len(f)] = np.frombuffer(f, np.uint8)
     out_off = np.zeros(n, np.uint64)
     out_cap = np.array(caps, np.uint64)
-    pos = 7
+    pos = 7 if guard is None else 0
+    end = 0
     for i in range(n):
         out_off[i] = pos
+        end = pos + int(caps[i])
         pos += int(caps[i]) + 9
-    obuf = np.full(pos + 64, 0xEE, np.uint8)
+    if guard is None:
+        obuf = np.full(pos + 64, 0xEE, np.uint8)
+        oaddr = obuf.ctypes.data
+    else:
+        _keep_out = Guarded(end, guard, fill=0xEE)
+        obuf, oaddr = _keep_out.view, _keep_out.addr
     out_len = np.zeros(n, np.uint64)
     status = np.zeros(n, np.int32)
-    rc = lib().emu_decompress(ibuf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, n, obuf.ctypes.data, out_off.ctypes.data, out_cap.ctypes.data,
+    rc = lib().emu_decompress(iaddr, in_off.ctypes.data, in_len.ctypes.data, n, oaddr, out_off.ctypes.data, out_cap.ctypes.data,
                               out_len.ctypes.data, status.ctypes.data)
     outs = [obuf[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
     for i in range(n):   # nothing written past the capacity

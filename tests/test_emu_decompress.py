@@ -14,11 +14,9 @@ def test_emu_decode_reference_frames(small_cases):
     names = list(small_cases)
     frames = [ref.lz4f_compress(small_cases[k]) for k in names]       # == lz4.frame.compress(data): linked blocks
     rc, outs, status = emulib.decompress(frames, [len(small_cases[k]) for k in names])
+    assert rc == 0
     for k, o, s, f in zip(names, outs, status, frames):
-        if len(small_cases[k]) == 0:
-            assert s == 10   # liblz4 writes no content size for empty input: unsupported by design, reported not crashed
-            continue
-        assert s == 0 and o == small_cases[k], k
+        assert s == 0 and o == small_cases[k], k      # includes the empty chunk, whose frame has no content size
 
 
 def test_emu_decode_own_frames_roundtrip(small_cases):
@@ -82,3 +80,31 @@ def test_emu_decode_full_chunk():
     d = synth.silesia_like(2 << 20, config_id=2).tobytes()
     rc, outs, status = emulib.decompress([ref.lz4f_compress(d)], [len(d)])
     assert rc == 0 and outs[0] == d
+
+
+def test_emu_decode_frames_without_content_size():
+    """python-lz4 store_size=False / liblz4 streaming producers: the length comes out of the last block."""
+    rng = synth.rng_for(21)
+    datas = [b"", b"a", synth.gen_class("text", 1000, rng).tobytes(), synth.gen_class("records", 65536, rng).tobytes(),
+             synth.gen_class("text", 65537, rng).tobytes(), synth.gen_class("random", 150_000, rng).tobytes(), bytes(200_001)]
+    for linked in (True, False):
+        frames = [ref.lz4f_compress(d, store_size=False, block_linked=linked) for d in datas]
+        assert all(not (f[4] & 0x08) for f in frames)
+        # capacity == exact length, and capacity with slack: both must report the true decoded length
+        for slack in (0, 77, 70_000):
+            rc, outs, status = emulib.decompress(frames, [len(d) + slack for d in datas])
+            assert rc == 0 and status == [0] * len(datas), (linked, slack, status)
+            assert outs == datas
+        # one byte short: rejected, nothing reported
+        short = [i for i, d in enumerate(datas) if len(d)]
+        rc, outs, status = emulib.decompress([frames[i] for i in short], [len(datas[i]) - 1 for i in short])
+        assert rc == -8 and all(s != 0 for s in status) and all(o == b"" for o in outs)
+
+
+@pytest.mark.parametrize("bsid,bmax", [(5, 256 << 10), (6, 1 << 20), (7, 4 << 20)])
+def test_emu_decode_large_block_sizes(bsid, bmax):
+    d = synth.gen_class("records", bmax + 12345, synth.rng_for(22, bsid)).tobytes()
+    frames = [ref.lz4f_compress(d, block_size_id=bsid), ref.lz4f_compress(d, block_size_id=bsid, block_linked=False),
+              ref.lz4f_compress(d, store_size=False, block_size_id=bsid)]
+    rc, outs, status = emulib.decompress(frames, [len(d)] * 3)
+    assert rc == 0 and status == [0, 0, 0] and outs == [d, d, d]

@@ -23,7 +23,7 @@ def ctx():
 
 
 def test_decode_reference_and_own_frames(ctx, small_cases):
-    names = [k for k in small_cases if len(small_cases[k])]
+    names = list(small_cases)                                           # includes the empty chunk (frame without content size)
     chunks = [small_cases[k] for k in names]
     linked = [ref.lz4f_compress(c) for c in chunks]                     # what a reference sender puts on the wire
     own = [r.frame for r in ctx.process_batch(chunks, flags=1)]         # what the gpu_compress operator produces
@@ -79,3 +79,26 @@ def test_device_roundtrip_stream(ctx):
     olen = ctx.decompress_device(d_fr.data_ptr(), off * stride, flen, d_out.data_ptr(), off * cb, np.full(n, cb, np.uint64))
     assert (olen == cb).all() and torch.equal(d_in, d_out)
     assert ctx.decompress_ms(reset=False) > 0
+
+
+def test_decode_frames_without_content_size_and_large_blocks(ctx):
+    """python-lz4's store_size=False / block_size knobs: a receiver must not depend on the sender's defaults."""
+    rng = synth.rng_for(21)
+    datas = [b"", b"a", synth.gen_class("text", 65537, rng).tobytes(), synth.gen_class("random", 150_000, rng).tobytes(), bytes(200_001),
+             synth.gen_class("records", (4 << 20) + 12345, rng).tobytes()]
+    for kw in ({"store_size": False}, {"store_size": False, "block_linked": False}, {"block_size_id": 7}, {"store_size": False, "block_size_id": 6}):
+        frames = [ref.lz4f_compress(d, **kw) for d in datas]
+        assert ctx.decompress_batch(frames, [len(d) + 100 for d in datas]) == datas, kw
+        assert ctx.decompress_batch(frames, [len(d) for d in datas]) == datas, kw
+
+
+def test_chunks_ending_in_long_runs(ctx):
+    """Regression: the match finder used to read past the end of a chunk whose last block ends in a long match
+    (zero pages); results were right, the read was not.  Parity here; the bounds themselves are policed under the
+    emulator with guard pages (tests/test_emu_guard.py)."""
+    import hashlib
+    rng = synth.rng_for(33)
+    chunks = [bytes(65536), bytes(8 << 20), synth.gen_class("text", 1 << 20, rng).tobytes() + bytes(65536 + 17),
+              synth.gen_class("random", 100_000, rng).tobytes() + b"\x07" * 70_000]
+    for c, r in zip(chunks, ctx.process_batch(chunks, flags=3)):
+        assert ref.lz4f_decompress(r.frame, len(c)) == c and r.md5 == hashlib.md5(c).digest()
