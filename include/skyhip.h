@@ -87,6 +87,14 @@ int  skyhip_process_batch(skyhip_ctx* ctx, int n,
                           uint32_t* const* cuts, const size_t* cuts_cap, size_t* n_cuts,
                           uint32_t flags);
 
+/* Pinned (DMA-able) host memory for the buffers handed to skyhip_process_batch / skyhip_decompress_batch: with it the
+ * H2D/D2H copies are asynchronous and overlap the kernels of the neighbouring sub-batch; pageable buffers are accepted
+ * but staged synchronously by the runtime.  This is the zero-copy hand-off of SURVEY.md 8f item 2: the operator reads
+ * `<chunk_id>.chunk` straight into such a buffer instead of `f.read()` at gateway_operator.py:350-351.
+ * Blocks still alive at skyhip_destroy are freed there. */
+int  skyhip_host_alloc(skyhip_ctx* ctx, size_t bytes, void** out);
+int  skyhip_host_free(skyhip_ctx* ctx, void* p);
+
 /* Device-resident batch (kernel-only path: inputs already in HBM, PCIe excluded).
  * d_in / d_out are DEVICE pointers on ctx's device; in_off/in_len/out_off/out_cap are HOST arrays of
  * byte offsets into d_in / d_out.  out_len (host, may be NULL) and md5 (host, may be NULL) are filled

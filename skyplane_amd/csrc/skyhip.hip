@@ -146,8 +146,11 @@ struct skyhip_ctx {
     DevBuf<uint8_t> d_scratch;
     DevBuf<uint32_t> d_csize, d_blk_word;
     DevBuf<sky_u64> d_blk_dst;
-    // host-batch staging
+    // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
     DevBuf<uint8_t> d_stage_in, d_stage_out;
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    std::vector<hipEvent_t> ev_up;    // upload-complete event per LZ4 sub-batch of a group (grow-only)
+    std::vector<void*> host_allocs;   // skyhip_host_alloc'ed blocks still alive (freed by skyhip_destroy at the latest)
 #ifdef SKY_WITH_CDC
     SkyCdcState cdc;   // CDC / dedup state
 #endif
@@ -246,6 +249,8 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_lz4, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_md5, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_cdc, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
         const size_t nb = (size_t)max_batch * c->blocks_per_chunk;
         HIPCHK(c, c->d_scratch.ensure(nb * SKY_LZ4_SLOT));
         HIPCHK(c, c->d_csize.ensure(nb));
@@ -276,12 +281,18 @@ void skyhip_destroy(skyhip_ctx* c) {
     if (c->s_lz4) (void)hipStreamSynchronize(c->s_lz4);
     if (c->s_md5) (void)hipStreamSynchronize(c->s_md5);
     if (c->s_cdc) (void)hipStreamSynchronize(c->s_cdc);
+    if (c->s_up) (void)hipStreamSynchronize(c->s_up);
+    if (c->s_down) (void)hipStreamSynchronize(c->s_down);
     ev_collect(c);
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
     c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release();
     c->d_stage_in.release(); c->d_stage_out.release();
+    for (hipEvent_t e : c->ev_up) (void)hipEventDestroy(e);
+    c->ev_up.clear();
+    for (void* p : c->host_allocs) (void)hipHostFree(p);
+    c->host_allocs.clear();
     c->dec.release();
 #ifdef SKY_WITH_CDC
     sky_cdc_state_release(&c->cdc);
@@ -291,14 +302,28 @@ void skyhip_destroy(skyhip_ctx* c) {
     if (c->s_lz4) (void)hipStreamDestroy(c->s_lz4);
     if (c->s_md5) (void)hipStreamDestroy(c->s_md5);
     if (c->s_cdc) (void)hipStreamDestroy(c->s_cdc);
+    if (c->s_up) (void)hipStreamDestroy(c->s_up);
+    if (c->s_down) (void)hipStreamDestroy(c->s_down);
     delete c;
 }
 
 void skyhip_get_timing(skyhip_ctx* c, skyhip_timing* out) { if (c && out) *out = c->tm; }
 void skyhip_reset_timing(skyhip_ctx* c) { if (c) memset(&c->tm, 0, sizeof c->tm); }
 
-int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
-                          const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags) {
+// Hooks that turn the device-resident call into the middle of the host-buffer pipeline (skyhip_process_batch):
+// the chunks of LZ4 sub-batch s become resident when ev_up[s] fires (H2D copies queued on the context's upload stream),
+// and as soon as a sub-batch's frames are laid out they start travelling to host_out[] on the download stream, while
+// later sub-batches still upload / compress and the one whole-batch MD5 launch runs beside all of it.
+struct SkyPipe {
+    const hipEvent_t* ev_up;     // [number of LZ4 sub-batches]; recorded in order on one stream
+    int n_sub;
+    uint8_t* const* host_out;    // [n] destination of each frame (null when SKYHIP_F_LZ4 is not set)
+    size_t* host_out_len;        // [n]
+};
+
+static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
+                            const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags,
+                            const SkyPipe* pipe) {
     if (!c || n < 0 || (n > 0 && (!d_in || !in_off || !in_len))) return SKYHIP_E_INVAL;
     if ((flags & SKYHIP_F_LZ4) && n > 0 && (!d_out || !out_off || !out_cap)) return SKYHIP_E_INVAL;
     if ((flags & SKYHIP_F_DEDUP) && !(flags & SKYHIP_F_CDC)) return SKYHIP_E_INVAL;
@@ -332,9 +357,12 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
     HIPCHK(c, hipEventRecord(meta_ready, c->s_lz4));
 
     int rc = 0;
+    std::vector<hipEvent_t> ev_done;     // pipe mode: sub-batch s laid out and its frame lengths on the host
+    struct EvGuard { std::vector<hipEvent_t>& v; ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); } } ev_guard{ev_done};
     // ---- MD5 first: few, long-running waves; they become resident and the LZ4 grid fills the rest ----
     if (flags & SKYHIP_F_MD5) {
         HIPCHK(c, hipStreamWaitEvent(c->s_md5, meta_ready, 0));
+        if (pipe) HIPCHK(c, hipStreamWaitEvent(c->s_md5, pipe->ev_up[pipe->n_sub - 1], 0));   // needs every chunk resident
         SkyMd5Args ma;
         ma.in = (const uint8_t*)d_in; ma.off = c->d_in_off.p; ma.len = c->d_in_len.p; ma.n = (uint32_t)N; ma.digest = c->d_md5.p;
         EvPair ep;
@@ -351,6 +379,7 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
         return SKYHIP_E_INVAL;
 #else
         HIPCHK(c, hipStreamWaitEvent(c->s_cdc, meta_ready, 0));
+        if (pipe) HIPCHK(c, hipStreamWaitEvent(c->s_cdc, pipe->ev_up[pipe->n_sub - 1], 0));
         EvPair ep;
         if ((rc = ev_begin(c, c->s_cdc, K_CDC, &ep))) return rc;
         rc = sky_cdc_run(&c->cdc, c->s_cdc, (const uint8_t*)d_in, c->d_in_off.p, c->d_in_len.p, c->h_in_len.p, (uint32_t)N,
@@ -364,6 +393,7 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
         for (size_t c0 = 0; c0 < N; c0 += (size_t)c->max_batch) {
             const size_t nc = (N - c0 < (size_t)c->max_batch) ? N - c0 : (size_t)c->max_batch;
             const uint32_t nb = c->h_blk_prefix.p[c0 + nc] - c->h_blk_prefix.p[c0];
+            if (pipe) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, pipe->ev_up[c0 / (size_t)c->max_batch], 0));
             uint64_t sub_bytes = 0;
             for (size_t i = c0; i < c0 + nc; i++) sub_bytes += c->h_in_len.p[i];
             SkyLz4Args la;
@@ -400,8 +430,25 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
                 HIPCHK(c, hipGetLastError());
                 if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
             }
+            if (pipe) {
+                HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p + c0, c->d_frame_len.p + c0, nc * 8, hipMemcpyDeviceToHost, c->s_lz4));
+                hipEvent_t e;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ev_done.push_back(e);
+                HIPCHK(c, hipEventRecord(e, c->s_lz4));
+            }
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_lz4));
+        if (!pipe) HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_lz4));
+        // pipe mode: ship each sub-batch's frames as soon as their lengths are known; later sub-batches keep computing
+        for (size_t sidx = 0; sidx < ev_done.size(); sidx++) {
+            HIPCHK(c, hipEventSynchronize(ev_done[sidx]));
+            const size_t c0 = sidx * (size_t)c->max_batch, nc = (N - c0 < (size_t)c->max_batch) ? N - c0 : (size_t)c->max_batch;
+            for (size_t i = c0; i < c0 + nc; i++) {
+                const sky_u64 fl = c->h_frame_len.p[i];
+                pipe->host_out_len[i] = (size_t)fl;
+                HIPCHK(c, hipMemcpyAsync(pipe->host_out[i], (const uint8_t*)d_out + out_off[i], fl, hipMemcpyDeviceToHost, c->s_down));
+            }
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->s_lz4));
     HIPCHK(c, hipStreamSynchronize(c->s_md5));
@@ -421,6 +468,45 @@ int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t
     return SKYHIP_OK;
 }
 
+int skyhip_process_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
+                          const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, uint8_t (*md5)[16], uint32_t flags) {
+    return sky_process_impl(c, n, d_in, in_off, in_len, d_out, out_off, out_cap, out_len, md5, flags, nullptr);
+}
+
+int skyhip_host_alloc(skyhip_ctx* c, size_t bytes, void** out) {
+    if (!c || !out || bytes == 0) return SKYHIP_E_INVAL;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->dev));
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    c->host_allocs.push_back(p);
+    *out = p;
+    return SKYHIP_OK;
+}
+
+int skyhip_host_free(skyhip_ctx* c, void* p) {
+    if (!c) return SKYHIP_E_INVAL;
+    if (!p) return SKYHIP_OK;
+    for (size_t i = 0; i < c->host_allocs.size(); i++) {
+        if (c->host_allocs[i] == p) {
+            c->host_allocs.erase(c->host_allocs.begin() + (long)i);
+            HIPCHK(c, hipSetDevice(c->dev));
+            HIPCHK(c, hipStreamSynchronize(c->s_up));      // no copy of ours may still be reading / writing it
+            HIPCHK(c, hipStreamSynchronize(c->s_down));
+            HIPCHK(c, hipHostFree(p));
+            return SKYHIP_OK;
+        }
+    }
+    return SKYHIP_E_INVAL;   // not one of ours
+}
+
+// Host-buffer batch.  The chunks of a call are staged in HBM together (up to SKYHIP_STAGE_BYTES, default 32 GiB --
+// a sliver of 288 GB; larger calls run as consecutive groups) so that whole-chunk MD5, a ~0.1 s serial chain per chunk
+// whatever the batch size, is ONE launch for the group.  Inside a group everything is a pipeline: H2D copies are queued
+// per LZ4 sub-batch on s_up, the compressor starts on sub-batch s when its upload event fires, and each sub-batch's
+// frames start their D2H on s_down as soon as they are laid out (SkyPipe above).  The copies are truly asynchronous
+// only for pinned host memory (skyhip_host_alloc, hipHostMalloc/hipHostRegister); pageable buffers work, but the
+// runtime then stages them synchronously and the pipeline degenerates to upload-all, compute, download.
 int skyhip_process_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
                          size_t* out_len, uint8_t (*md5)[16], uint32_t* const* cuts, const size_t* cuts_cap, size_t* n_cuts, uint32_t flags) {
     if (!c || n < 0) return SKYHIP_E_INVAL;
@@ -429,39 +515,73 @@ int skyhip_process_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const s
     if ((flags & SKYHIP_F_LZ4) && (!out || !out_cap || !out_len)) return SKYHIP_E_INVAL;
     if ((flags & SKYHIP_F_MD5) && !md5) return SKYHIP_E_INVAL;
     if ((flags & SKYHIP_F_CDC) && (!cuts || !cuts_cap || !n_cuts)) return SKYHIP_E_INVAL;
+    // validate everything before the first copy is queued: no early return may leave a copy in flight
+    size_t longest = 0;
+    for (int i = 0; i < n; i++) {
+        if (in_len[i] > c->max_chunk) return SKYHIP_E_TOOBIG;
+        if (in_len[i] && !in[i]) return SKYHIP_E_INVAL;
+        if ((flags & SKYHIP_F_LZ4) && !out[i]) return SKYHIP_E_INVAL;
+        if ((flags & SKYHIP_F_LZ4) && out_cap[i] < skyhip_frame_bound(in_len[i])) return SKYHIP_E_CAP;
+        if (in_len[i] > longest) longest = in_len[i];
+    }
     HIPCHK(c, hipSetDevice(c->dev));
-    const size_t in_stride = (c->max_chunk + 255) & ~(size_t)255;
-    const size_t out_stride = (skyhip_frame_bound(c->max_chunk) + 255) & ~(size_t)255;
-    HIPCHK(c, c->d_stage_in.ensure(in_stride * (size_t)c->max_batch));
-    if (flags & SKYHIP_F_LZ4) HIPCHK(c, c->d_stage_out.ensure(out_stride * (size_t)c->max_batch));
-    std::vector<uint64_t> off_in(c->max_batch), len_in(c->max_batch), off_out(c->max_batch), cap_out(c->max_batch), flen(c->max_batch);
-    for (int c0 = 0; c0 < n; c0 += c->max_batch) {
-        const int nc = (n - c0 < c->max_batch) ? n - c0 : c->max_batch;
-        for (int i = 0; i < nc; i++) {
-            const size_t L = in_len[c0 + i];
-            if (L > c->max_chunk) return SKYHIP_E_TOOBIG;
-            if (L && !in[c0 + i]) return SKYHIP_E_INVAL;
-            if ((flags & SKYHIP_F_LZ4) && out_cap[c0 + i] < skyhip_frame_bound(L)) return SKYHIP_E_CAP;
-            off_in[i] = in_stride * (size_t)i; len_in[i] = L; off_out[i] = out_stride * (size_t)i; cap_out[i] = out_stride;
-            if (L) HIPCHK(c, hipMemcpyAsync(c->d_stage_in.p + off_in[i], in[c0 + i], L, hipMemcpyHostToDevice, c->s_lz4));
-        }
-        HIPCHK(c, hipStreamSynchronize(c->s_lz4));
-        int rc = skyhip_process_device(c, nc, c->d_stage_in.p, off_in.data(), len_in.data(), c->d_stage_out.p, off_out.data(), cap_out.data(),
-                                       flen.data(), md5 ? md5 + c0 : nullptr, flags);
-        if (rc) return rc;
-        if (flags & SKYHIP_F_LZ4) {
-            for (int i = 0; i < nc; i++) {
-                out_len[c0 + i] = (size_t)flen[i];
-                HIPCHK(c, hipMemcpyAsync(out[c0 + i], c->d_stage_out.p + off_out[i], flen[i], hipMemcpyDeviceToHost, c->s_lz4));
+    const size_t in_stride = (longest + 255) & ~(size_t)255;
+    const size_t out_stride = (flags & SKYHIP_F_LZ4) ? ((skyhip_frame_bound(longest) + 255) & ~(size_t)255) : 0;
+    size_t budget = (size_t)32 << 30;
+    if (const char* e = getenv("SKYHIP_STAGE_BYTES")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) budget = (size_t)v; }
+    size_t group = budget / (in_stride + out_stride + 1);
+    // the CDC results of a call describe one device launch (see skyhip_cdc_results): keep that contract at max_batch
+    if (group < (size_t)c->max_batch || (flags & SKYHIP_F_CDC)) group = (size_t)c->max_batch;
+    if (group > (size_t)n) group = (size_t)n;
+    HIPCHK(c, c->d_stage_in.ensure(in_stride * group + 256));
+    if (flags & SKYHIP_F_LZ4) HIPCHK(c, c->d_stage_out.ensure(out_stride * group + 256));
+    const size_t max_sub = (group + (size_t)c->max_batch - 1) / (size_t)c->max_batch;
+    while (c->ev_up.size() < max_sub) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_up.push_back(e);
+    }
+    std::vector<uint64_t> off_in(group), len_in(group), off_out(group), cap_out(group), flen(group);
+    for (size_t i = 0; i < group; i++) { off_in[i] = in_stride * i; off_out[i] = out_stride * i; cap_out[i] = out_stride; }
+
+    int rc = SKYHIP_OK;
+    hipError_t he = hipSuccess;
+    const char* what = "";
+    for (size_t c0 = 0; c0 < (size_t)n && rc == SKYHIP_OK && he == hipSuccess; c0 += group) {
+        const size_t nc = ((size_t)n - c0 < group) ? (size_t)n - c0 : group;
+        const int n_sub = (int)((nc + (size_t)c->max_batch - 1) / (size_t)c->max_batch);
+        // generation reuse: the previous group's downloads must have left the staging area
+        if (c0) { he = hipStreamSynchronize(c->s_down); if (he != hipSuccess) { what = "hipStreamSynchronize(s_down)"; break; } }
+        for (int sb = 0; sb < n_sub && he == hipSuccess; sb++) {
+            const size_t lo = (size_t)sb * (size_t)c->max_batch, hi = (lo + (size_t)c->max_batch < nc) ? lo + (size_t)c->max_batch : nc;
+            for (size_t i = lo; i < hi && he == hipSuccess; i++) {
+                len_in[i] = in_len[c0 + i];
+                if (in_len[c0 + i]) {
+                    he = hipMemcpyAsync(c->d_stage_in.p + off_in[i], in[c0 + i], in_len[c0 + i], hipMemcpyHostToDevice, c->s_up);
+                    if (he != hipSuccess) what = "hipMemcpyAsync(H2D)";
+                }
             }
-            HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+            if (he == hipSuccess) { he = hipEventRecord(c->ev_up[sb], c->s_up); if (he != hipSuccess) what = "hipEventRecord(ev_up)"; }
         }
+        if (he != hipSuccess) break;
+        SkyPipe pipe;
+        pipe.ev_up = c->ev_up.data(); pipe.n_sub = n_sub;
+        pipe.host_out = (flags & SKYHIP_F_LZ4) ? out + c0 : nullptr;
+        pipe.host_out_len = (flags & SKYHIP_F_LZ4) ? out_len + c0 : nullptr;
+        rc = sky_process_impl(c, (int)nc, c->d_stage_in.p, off_in.data(), len_in.data(), (flags & SKYHIP_F_LZ4) ? c->d_stage_out.p : nullptr, off_out.data(),
+                              cap_out.data(), flen.data(), md5 ? md5 + c0 : nullptr, flags, &pipe);
 #ifdef SKY_WITH_CDC
-        if (flags & SKYHIP_F_CDC) {
-            rc = sky_cdc_copy_cuts(&c->cdc, nc, cuts + c0, cuts_cap + c0, n_cuts + c0);
-            if (rc) return rc;
-        }
+        if (rc == SKYHIP_OK && (flags & SKYHIP_F_CDC)) rc = sky_cdc_copy_cuts(&c->cdc, (int)nc, cuts + c0, cuts_cap + c0, n_cuts + c0);
 #endif
+    }
+    // the caller's buffers are ours until both copy streams are idle, on every path
+    const hipError_t e1 = hipStreamSynchronize(c->s_up), e2 = hipStreamSynchronize(c->s_down);
+    if (he == hipSuccess && e1 != hipSuccess) { he = e1; what = "hipStreamSynchronize(s_up)"; }
+    if (he == hipSuccess && e2 != hipSuccess) { he = e2; what = "hipStreamSynchronize(s_down)"; }
+    if (rc != SKYHIP_OK) return rc;
+    if (he != hipSuccess) {
+        snprintf(c->hip_err, sizeof(c->hip_err), "%s: %s (process_batch)", what, hipGetErrorString(he));
+        return he == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP;
     }
     return SKYHIP_OK;
 }

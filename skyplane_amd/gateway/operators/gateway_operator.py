@@ -144,6 +144,7 @@ class GatewayHipCompress(GatewayOperator):
         self.idle_sleep_s = idle_sleep_s
         self._context_factory = context_factory or _default_context_factory
         self._ctx = None
+        self._arenas = {}
 
     # -- process-local ---------------------------------------------------------------------------------
     def _context(self):
@@ -156,16 +157,59 @@ class GatewayHipCompress(GatewayOperator):
     def _flags(self) -> int:
         return 1 | (2 if self.compute_md5 else 0) | (4 if self.cdc else 0) | (8 if self.dedup and self.cdc else 0)
 
-    def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
-        datas = []
-        for cr in chunk_reqs:
+    def _arena(self, ctx, which: str, nbytes: int):
+        """Grow-only pinned staging area of this worker (skyhip_host_alloc): chunk files are read straight into it
+        and the frames come back into it, so the only host copies left are the page-cache read and write."""
+        cur = self._arenas.get(which)
+        if cur is None or cur.size < nbytes:
+            if cur is not None:
+                ctx.release_pinned(cur)
+            cur = ctx.pinned_buffer(max(nbytes, 1))
+            self._arenas[which] = cur
+        return cur
+
+    def _read_chunks(self, chunk_reqs: List[ChunkRequest], ctx):
+        """Raw bytes of every request.  With a real context: views of the pinned arena filled by readinto (zero-copy
+        hand-off); otherwise plain bytes, as the reference reads them at gateway_operator.py:350-351."""
+        sizes = [int(cr.chunk.chunk_length_bytes) for cr in chunk_reqs]
+        pinned = hasattr(ctx, "pinned_buffer")
+        arena, pos, datas = None, 0, []
+        if pinned:
+            arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
+        for cr, size in zip(chunk_reqs, sizes):
             path = self.chunk_store.get_chunk_file_path(cr.chunk.chunk_id)
             with open(path, "rb") as f:
-                data = f.read()
+                if not pinned:
+                    data = f.read()
+                    got = len(data)
+                else:
+                    data = arena[pos:pos + size]
+                    pos += (size + 255) & ~255
+                    got, view = 0, memoryview(data)
+                    while got < size:
+                        k = f.readinto(view[got:])
+                        if not k:
+                            break
+                        got += k
+                    got += len(f.read(1))     # a longer file is as wrong as a shorter one
             # same invariant GatewaySender.process asserts at gateway_operator.py:352
-            assert len(data) == cr.chunk.chunk_length_bytes, f"chunk {cr.chunk.chunk_id} has size {len(data)} but should be {cr.chunk.chunk_length_bytes}"
+            assert got == size, f"chunk {cr.chunk.chunk_id} has size {got}{'+' if got > size else ''} but should be {size}"
             datas.append(data)
-        results = self._context().process_batch(datas, flags=self._flags())
+        return datas
+
+    def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
+        ctx = self._context()
+        datas = self._read_chunks(chunk_reqs, ctx)
+        if hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound"):
+            bounds = [ctx.frame_bound(len(d)) for d in datas]
+            out = self._arena(ctx, "out", sum((b + 255) & ~255 for b in bounds))
+            views, pos = [], 0
+            for b in bounds:
+                views.append(out[pos:pos + b])
+                pos += (b + 255) & ~255
+            results = ctx.process_batch(datas, flags=self._flags(), frames_into=views)
+        else:
+            results = ctx.process_batch(datas, flags=self._flags())
         self._last_metadata = []
         for cr, data, res in zip(chunk_reqs, datas, results):
             cid = cr.chunk.chunk_id
@@ -221,5 +265,6 @@ class GatewayHipCompress(GatewayOperator):
 
     def worker_exit(self, worker_id: int):
         if self._ctx is not None:
+            self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
             self._ctx = None

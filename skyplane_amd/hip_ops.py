@@ -43,11 +43,13 @@ class SkyHipContext:
         if rc != 0:
             raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode())
         self._h = h
+        self._pinned = {}
         self.device_id, self.max_chunk_bytes, self.max_batch = device_id, max_chunk_bytes, max_batch
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
+            self._pinned.clear()            # skyhip_destroy frees every block still alive
             self._lib.skyhip_destroy(self._h)
             self._h = None
 
@@ -68,8 +70,31 @@ class SkyHipContext:
             detail = self._lib.skyhip_last_hip_error(self._h).decode()
             raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode() + (f" [{detail}]" if detail else ""))
 
+    @staticmethod
+    def frame_bound(raw_len: int) -> int:
+        return frame_bound(raw_len)
+
+    # -- pinned host memory (zero-copy hand-off) ---------------------------------
+    def pinned_buffer(self, nbytes: int) -> np.ndarray:
+        """uint8 array over DMA-able host memory (skyhip_host_alloc).  Read chunk files straight into it
+        (``f.readinto(buf[a:b])``) and pass views to process_batch: the H2D/D2H copies then run asynchronously and
+        overlap the kernels of the neighbouring sub-batch.  Valid until release_pinned(buf) or close()."""
+        p = C.c_void_p()
+        self._check(self._lib.skyhip_host_alloc(self._h, int(nbytes), C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p.value))
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def release_pinned(self, buf: np.ndarray):
+        p = self._pinned.pop(buf.ctypes.data, None)
+        if p is not None and self._h:
+            self._check(self._lib.skyhip_host_free(self._h, C.c_void_p(p)))
+
     # -- host-buffer path (what the gateway operator uses) -------------------------------------------
-    def process_batch(self, chunks: Sequence, flags: int = F_LZ4 | F_MD5) -> List[ChunkResult]:
+    def process_batch(self, chunks: Sequence, flags: int = F_LZ4 | F_MD5, frames_into: Optional[Sequence[np.ndarray]] = None) -> List[ChunkResult]:
+        """chunks: bytes-like objects or uint8 arrays (views of a pinned_buffer for the asynchronous path).
+        frames_into: optional uint8 arrays (>= frame_bound(len) each, ideally pinned views) that receive the frames;
+        ChunkResult.frame is then a view of them instead of a fresh bytes object (no copy on the way out)."""
         n = len(chunks)
         if n == 0:
             return []
@@ -78,7 +103,12 @@ class SkyHipContext:
         in_len = (C.c_size_t * n)(*[a.size for a in arrs])
         outs, out_ptrs, out_cap, out_len = [], None, None, None
         if flags & F_LZ4:
-            outs = [np.empty(frame_bound(a.size), np.uint8) for a in arrs]
+            if frames_into is not None:
+                outs = list(frames_into)
+                if len(outs) != n or any(o.dtype != np.uint8 or not o.flags["C_CONTIGUOUS"] or not o.flags["WRITEABLE"] for o in outs):
+                    raise ValueError("frames_into: one writable contiguous uint8 array per chunk")
+            else:
+                outs = [np.empty(frame_bound(a.size), np.uint8) for a in arrs]
             out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
             out_cap = (C.c_size_t * n)(*[o.size for o in outs])
             out_len = (C.c_size_t * n)()
@@ -94,7 +124,10 @@ class SkyHipContext:
         self._check(rc)
         res = []
         for i in range(n):
-            res.append(ChunkResult(frame=outs[i][: out_len[i]].tobytes() if flags & F_LZ4 else None,
+            frame = None
+            if flags & F_LZ4:
+                frame = outs[i][: out_len[i]] if frames_into is not None else outs[i][: out_len[i]].tobytes()
+            res.append(ChunkResult(frame=frame,
                                    md5=md5[i].tobytes() if md5 is not None else None,
                                    cuts=cuts[i][: n_cuts[i]].copy() if flags & F_CDC else None))
         return res

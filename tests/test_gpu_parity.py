@@ -242,3 +242,47 @@ def test_reference_default_chunk_size_64MiB_unaligned_device_offsets():
         d_back = torch.zeros(big.size + small.size + 64, dtype=torch.uint8, device="cuda")
         olen = c.decompress_device(d_out.data_ptr(), out_off, out_len, d_back.data_ptr(), in_off, in_len)
         assert (olen == in_len).all() and torch.equal(d_back[3:3 + big.size].cpu(), torch.from_numpy(big))
+
+
+def test_host_batch_pinned_buffers_and_pipelined_sub_batches(monkeypatch):
+    """skyhip_process_batch with n > max_batch: one resident group whose LZ4 sub-batches start as their uploads land
+    and whose frames leave as they are laid out; with a tiny SKYHIP_STAGE_BYTES the same call runs as several
+    consecutive groups reusing the staging area.  Pinned (skyhip_host_alloc) and pageable buffers must give the same
+    frames, and every frame/digest must be right."""
+    import hashlib
+    from skyplane_amd import hip_ops
+
+    rng = synth.rng_for(41)
+    sizes = [1 << 20, 0, 70_001, 65536, 13, (1 << 20) - 1, 300_000, 1, 65537, 999_999, 4096]
+    chunks = [synth.gen_class(synth.CLASSES[i % len(synth.CLASSES)], s, rng).tobytes() if s else b"" for i, s in enumerate(sizes)]
+    with hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=1 << 20, max_batch=4) as c:
+        plain = c.process_batch(chunks, flags=3)
+        arena_in = c.pinned_buffer(sum((s + 255) & ~255 for s in sizes) + 256)
+        bounds = [c.frame_bound(s) for s in sizes]
+        arena_out = c.pinned_buffer(sum((b + 255) & ~255 for b in bounds))
+        views_in, views_out, pi, po = [], [], 0, 0
+        for d, b in zip(chunks, bounds):
+            v = arena_in[pi:pi + len(d)]
+            v[:] = np.frombuffer(d, np.uint8)
+            views_in.append(v)
+            views_out.append(arena_out[po:po + b])
+            pi += (len(d) + 255) & ~255
+            po += (b + 255) & ~255
+        for stage in (None, str(3 << 20), None):          # one group / three groups of max_batch / one group again
+            if stage is None:
+                monkeypatch.delenv("SKYHIP_STAGE_BYTES", raising=False)
+            else:
+                monkeypatch.setenv("SKYHIP_STAGE_BYTES", stage)
+            arena_out[:] = 0
+            pinned = c.process_batch(views_in, flags=3, frames_into=views_out)
+            again = c.process_batch(chunks, flags=3)
+            for d, a, b, g in zip(chunks, plain, pinned, again):
+                assert bytes(b.frame) == a.frame == g.frame and a.md5 == b.md5 == g.md5 == hashlib.md5(d).digest()
+                assert ref.lz4f_decompress(a.frame, len(d)) == d
+        lz4_only = c.process_batch(views_in, flags=1, frames_into=views_out)
+        assert [bytes(r.frame) for r in lz4_only] == [r.frame for r in plain] and all(r.md5 is None for r in lz4_only)
+        md5_only = c.process_batch(chunks, flags=2)
+        assert [r.md5 for r in md5_only] == [r.md5 for r in plain]
+        c.release_pinned(arena_in)
+        with pytest.raises(hip_ops.SkyHipError):
+            c._check(c._lib.skyhip_host_free(c._h, 12345))          # not one of ours

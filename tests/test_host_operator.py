@@ -49,6 +49,38 @@ def _factory(dev, mc, mb):
     return _OracleContext(dev, mc, mb)
 
 
+class _ArenaContext(_OracleContext):
+    """Same double plus SkyHipContext's staging interface (pinned_buffer / release_pinned / frame_bound /
+    frames_into), over ordinary memory: exercises the operator's zero-copy read/write path on the CPU."""
+
+    def pinned_buffer(self, nbytes):
+        Path(os.environ["SKYTEST_DEVLOG"]).open("a").write(f"arena {nbytes}\n")
+        return np.full(nbytes, 0xCD, np.uint8)
+
+    def release_pinned(self, buf):
+        Path(os.environ["SKYTEST_DEVLOG"]).open("a").write(f"release {buf.size}\n")
+
+    @staticmethod
+    def frame_bound(n):
+        return 15 + n + 4 * ((n + 65535) // 65536) + 4
+
+    def process_batch(self, chunks, flags=3, frames_into=None):
+        from skyplane_amd.hip_ops import ChunkResult
+
+        assert frames_into is not None and all(isinstance(c, np.ndarray) for c in chunks)
+        res = []
+        for c, out in zip(chunks, frames_into):
+            f = np.frombuffer(ref.lz4f_compress_port(c.tobytes()), np.uint8)
+            assert out.size >= self.frame_bound(c.size)
+            out[: f.size] = f
+            res.append(ChunkResult(frame=out[: f.size], md5=ref.md5(c.tobytes()) if flags & 2 else None))
+        return res
+
+
+def _arena_factory(dev, mc, mb):
+    return _ArenaContext(dev, mc, mb)
+
+
 def _make_store(tmp_path, n, size=70_000):
     store = ChunkStore(tmp_path / "chunks")
     q_in, q_out = GatewayQueue(), GatewayQueue()
@@ -112,6 +144,35 @@ def test_operator_batches_shards_devices_and_writes_sidecars(tmp_path, monkeypat
         hip_sender.cleanup_sidecars(store, cr.chunk.chunk_id)
         hdr, payload = hip_sender.wire_payload(store, cr, 3)                                # no sidecar -> raw, like use_compression=False
         assert not hdr.is_compressed and payload == data and hdr.n_chunks_left_on_socket == 3
+
+
+def test_operator_zero_copy_staging_path(tmp_path, monkeypatch):
+    """With a context that offers pinned staging the operator reads chunk files straight into the arena and writes
+    the frames out of it; arenas grow, never shrink; results are what the plain path produces."""
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    store, q_in, q_out, reqs = _make_store(tmp_path, 7, size=70_001)         # odd size: views are 256-byte aligned, lengths are not
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "local:test", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=3, device_ids=[0],
+                            context_factory=_arena_factory)
+    op.worker_id = 0
+    crs = [cr for cr, _ in reqs]
+    assert op.process_batch(crs[:2]) == [True, True]
+    assert op.process_batch(crs[2:5]) == [True] * 3                           # larger batch: both arenas are replaced by bigger ones
+    assert op.process_batch(crs[5:6]) == [True]                               # smaller batch: arenas are reused
+    assert op.process(crs[6]) is True
+    log = (tmp_path / "dev.log").read_text().split("\n")
+    assert sum(l.startswith("arena") for l in log) == 4 and sum(l.startswith("release") for l in log) == 2
+    for cr, data in reqs:
+        frame = store.get_compressed_file_path(cr.chunk.chunk_id).read_bytes()
+        assert ref.lz4f_decompress(frame, len(data)) == data
+        assert hip_sender.chunk_digest(store, cr.chunk.chunk_id) == hashlib.md5(data).digest()
+    assert [m["uncompressed_size_bytes"] for m in op._last_metadata] == [70_001]
+    # size invariant of gateway_operator.py:352, both directions
+    for bad in (b"short", reqs[0][1] + b"x"):
+        store.get_chunk_file_path(crs[0].chunk.chunk_id).write_bytes(bad)
+        with pytest.raises(AssertionError, match="should be 70001"):
+            op.process_batch(crs[:1])
+    op.worker_exit(0)
 
 
 def test_operator_error_path_matches_reference(tmp_path, monkeypatch):
