@@ -36,25 +36,28 @@ for abl in [int(x) for x in os.environ.get("ABLS", "0,1,2,4,5,7,15").split(",")]
 # CDC stage alone (no LZ4/MD5 co-running)
 os.environ["SKYHIP_ABLATE"] = "0"
 zero = np.zeros(n, np.uint64)
-ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_CDC | hip_ops.F_DEDUP)
-ctx.dedup_reset(); ctx.reset_timing()
-for _ in range(2):
+if not os.environ.get("DEC_ONLY"):
+  ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_CDC | hip_ops.F_DEDUP)
+  ctx.dedup_reset(); ctx.reset_timing()
+  for _ in range(2):
     ctx.dedup_reset()
     ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_CDC | hip_ops.F_DEDUP)
-t = ctx.timing()
-print(f"cdc alone {t.cdc_ms/2:8.2f} ms -> {n*cb/(t.cdc_ms/2e3)/1e9:7.1f} GB/s", flush=True)
-ctx.reset_timing()
-for _ in range(2):
+  t = ctx.timing()
+  print(f"cdc alone {t.cdc_ms/2:8.2f} ms -> {n*cb/(t.cdc_ms/2e3)/1e9:7.1f} GB/s", flush=True)
+  ctx.reset_timing()
+  for _ in range(2):
     ctx.process_device(d_in.data_ptr(), in_off, in_len, 0, zero, zero, hip_ops.F_MD5)
-t = ctx.timing()
-print(f"md5 alone {t.md5_ms/2:8.2f} ms ({n} chunks)", flush=True)
+  t = ctx.timing()
+  print(f"md5 alone {t.md5_ms/2:8.2f} ms ({n} chunks)", flush=True)
 # decompression of the frames produced above (device resident)
 ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
 flen, _ = ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, hip_ops.F_LZ4)
 d_back = torch.empty(n * cb, dtype=torch.uint8, device="cuda")
 ctx.decompress_device(d_out.data_ptr(), out_off, flen, d_back.data_ptr(), in_off, in_len)
-ctx.decompress_ms(reset=True)
-for _ in range(2):
-    ctx.decompress_device(d_out.data_ptr(), out_off, flen, d_back.data_ptr(), in_off, in_len)
-ms = ctx.decompress_ms() / 2
-print(f"decompress {ms:8.2f} ms -> {n*cb/(ms/1e3)/1e9:7.1f} GB/s of output; roundtrip ok = {bool(torch.equal(d_back, d_in))}", flush=True)
+for lds in [int(x) for x in os.environ.get("DEC_LDS", "0").split(",")]:
+    os.environ["SKYHIP_DEC_LDS"] = str(lds)          # honoured by -DSKY_ABL=1 builds only: occupancy experiment
+    ctx.decompress_ms(reset=True)
+    for _ in range(2):
+        ctx.decompress_device(d_out.data_ptr(), out_off, flen, d_back.data_ptr(), in_off, in_len)
+    ms = ctx.decompress_ms() / 2
+    print(f"decompress (dyn LDS {lds:6d}) {ms:8.2f} ms -> {n*cb/(ms/1e3)/1e9:7.1f} GB/s of output; roundtrip ok = {bool(torch.equal(d_back, d_in))}", flush=True)

@@ -33,6 +33,15 @@ SKY_DEV int sky_wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(th
 SKY_DEV sky_u64 sky_ballot(bool p) { return __ballot(p); }
 SKY_DEV uint32_t sky_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// v_writelane_b32: lane `lane` (uniform) of the result holds the uniform value `val`, every other lane keeps `old`
+// (no clang builtin in this toolchain; the lane select goes through M0, which does not count against gfx9's
+// one-SGPR-per-VALU constant bus limit)
+SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                 : "+v"(old)
+                 : "s"(__builtin_amdgcn_readfirstlane((int)val)), "s"(__builtin_amdgcn_readfirstlane(lane)));   // M0 is reserved: the compiler keeps nothing live in it
+    return old;
+}
 // arbitrary gather across lanes (ds_bpermute_b32)
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 SKY_DEV void sky_syncthreads() { __syncthreads(); }

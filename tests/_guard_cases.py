@@ -97,6 +97,30 @@ def run_lz4d():
             frame = emulib.process([data], flags=1)[0][0]
             rc, outs, status = emulib.decompress([frame], [n], guard="end")
             assert rc == 0 and outs[0] == data, (n, name)
+    # corrupted frames: never a crash, never a byte outside the buffers, and the same accept/reject decision and the same
+    # bytes as liblz4 (lz4.frame.decompress, gateway_receiver.py:196)
+    rng = np.random.default_rng(20240917)
+    bases = []
+    for i, cls in enumerate(("text", "records", "binary", "sparse", "random")):
+        from skyplane_amd import synth
+        d = synth.gen_class(cls, 3000 + 500 * i, synth.rng_for(5, i)).tobytes()
+        bases += [(d, ref.lz4f_compress(d)), (d, ref.lz4f_compress_port(d))]
+    bases.append((bytes(70000), ref.lz4f_compress(bytes(70000))))
+    agree = 0
+    for it in range(200):
+        d, f = bases[it % len(bases)]
+        b = bytearray(f)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(15, len(b) - 4))] = int(rng.integers(0, 256))
+        fb = bytes(b)
+        try:
+            theirs = ref.lz4f_decompress(fb, len(d))
+        except ref.OracleError:
+            theirs = None
+        rc, outs, status = emulib.decompress([fb], [len(d)], guard="end" if it % 2 else "start")
+        ours = outs[0] if status[0] == 0 else None
+        assert ours == theirs, (it, status, None if theirs is None else len(theirs))
+        agree += 1
     print("OK lz4d")
 
 

@@ -46,6 +46,7 @@ SKY_DEV int sky_wave_in_block() { return emu_cur->tid >> 6; }
 SKY_DEV sky_u64 sky_ballot(bool p) { return emu_collective(EMU_BALLOT, p ? 1 : 0, 0); }
 SKY_DEV uint32_t sky_readlane(uint32_t v, int lane) { return (uint32_t)emu_collective(EMU_READLANE, v, (sky_u64)lane); }
 SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, v, (sky_u64)-1); }
+SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) { return sky_lane() == lane ? val : old; }
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective(EMU_SHFL, v, (sky_u64)(src & 63)); }
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
