@@ -119,6 +119,13 @@ int  skyhip_decompress_device(skyhip_ctx* ctx, int n,
 int  skyhip_decompress_batch(skyhip_ctx* ctx, int n,
                              const uint8_t* const* in, const size_t* in_len,
                              uint8_t* const* out, const size_t* out_cap, size_t* out_len, int32_t* status);
+/* Same, plus md5[i] = RFC 1321 digest of chunk i's DECODED bytes, computed on the device right after the decode --
+ * the receiver-side check the reference leaves as `# todo check hash` (gateway_receiver.py:231); md5 may be NULL.
+ * Needs out_cap[i] <= max_chunk_bytes of the context. */
+int  skyhip_decompress_batch_md5(skyhip_ctx* ctx, int n,
+                                 const uint8_t* const* in, const size_t* in_len,
+                                 uint8_t* const* out, const size_t* out_cap, size_t* out_len, int32_t* status,
+                                 uint8_t (*md5)[16]);
 double skyhip_decompress_ms(skyhip_ctx* ctx, int reset);   /* accumulated device time of scan + decode kernels */
 
 /* CDC results of the LAST device launch that had SKYHIP_F_CDC set (host copies).  skyhip_process_batch splits a batch

@@ -3,12 +3,14 @@
 itself cannot be imported offline):
 
     chunk files -> gpu_compress operator (forked worker, GPU) -> sender threads (sidecar frames, 53-byte headers)
-                -> loopback TCP, K connections -> receiver process (GPU decompress) -> chunk files
+                -> loopback TCP, K connections -> receiver process (deferred decode: payloads left as sidecars)
+                -> gpu_decompress operator (forked worker, GPU: batched decode + MD5 check on the device) -> chunk files
 
 Reports effective Gbit/s = raw bytes x 8 / wall time and verifies every destination file against its source.
 Plumbing (Python, tmpfs files, pickled queues, per-batch MD5 latency) bounds this number, not the kernels.
 """
 import argparse
+import dataclasses
 import hashlib
 import json
 import os
@@ -31,21 +33,13 @@ from skyplane_amd.chunk import Chunk, ChunkRequest  # noqa: E402
 from skyplane_amd.gateway.chunk_store import ChunkStore  # noqa: E402
 from skyplane_amd.gateway.gateway_queue import GatewayQueue  # noqa: E402
 from skyplane_amd.gateway.operators import hip_receiver, hip_sender  # noqa: E402
-from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress  # noqa: E402
+from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress, GatewayHipDecompress  # noqa: E402
 
 
-def receiver_main(dst_dir, port_q, done_q, n_conn, max_chunk):
-    """Destination gateway stand-in: one process, one thread per connection, one HIP context (created here, after fork)."""
-    from skyplane_amd import hip_ops
-
+def receiver_main(dst_dir, port_q, done_q, n_conn):
+    """Destination gateway's receiver stand-in: one process, one thread per connection, no GPU -- the decode is the
+    gpu_decompress operator's job (hip_receiver.recv_chunks(decompress=None))."""
     store = ChunkStore(dst_dir)
-    ctx = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=max_chunk, max_batch=4)
-    lock = threading.Lock()
-
-    def decompress(frame, raw_len):
-        with lock:
-            return ctx.decompress_batch([frame], [raw_len])[0]
-
     srv = socket.socket()
     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     srv.bind(("127.0.0.1", 0))
@@ -54,7 +48,7 @@ def receiver_main(dst_dir, port_q, done_q, n_conn, max_chunk):
 
     def serve(conn):
         with conn:
-            done_q.put(hip_receiver.recv_chunks(conn, store, decompress))
+            done_q.put(hip_receiver.recv_chunks(conn, store, None))
 
     threads = []
     for _ in range(n_conn):
@@ -65,7 +59,6 @@ def receiver_main(dst_dir, port_q, done_q, n_conn, max_chunk):
         threads.append(t)
     for t in threads:
         t.join()
-    ctx.close()
 
 
 def main():
@@ -80,6 +73,9 @@ def main():
         src, dst = ChunkStore(Path(tmp) / "src"), Path(tmp) / "dst"
         q_in, q_out = GatewayQueue(), GatewayQueue()
         src.add_partition("0", q_in)
+        dst_store = ChunkStore(dst)
+        dq_in, dq_out = GatewayQueue(), GatewayQueue()
+        dst_store.add_partition("0", dq_in)
         base = synth.mixed_chunks(4, size, config_id=4)
         reqs, digests = [], {}
         for i in range(args.chunks):
@@ -89,11 +85,13 @@ def main():
             digests[cid] = hashlib.md5(data).digest()
             reqs.append(ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0")))
         port_q, done_q = Queue(), Queue()
-        rx = Process(target=receiver_main, args=(dst, port_q, done_q, args.connections, size))
+        rx = Process(target=receiver_main, args=(dst, port_q, done_q, args.connections))
         rx.start()
         port = port_q.get(timeout=120)
         err_ev, err_q = Event(), Queue()
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=1, max_batch=args.max_batch, max_chunk_bytes=size, device_ids=[0])
+        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1, max_batch=args.max_batch,
+                                   max_chunk_bytes=size, device_ids=[0])
         # static split of the chunk set over the connections, like the reference's per-connection chunk lists
         shares = [reqs[k::args.connections] for k in range(args.connections)]
         ready = {}            # chunk_id -> ChunkRequest once the operator has produced its sidecar
@@ -118,11 +116,12 @@ def main():
         def drain_status():
             # the daemon's main loop does this (gateway_daemon.py:329-330); an undrained multiprocessing queue would
             # keep the operator's worker process from exiting
-            while not stop_drain.is_set() or not src.chunk_status_queue.empty():
-                try:
-                    status_records.append(src.chunk_status_queue.get(timeout=0.1))
-                except pyqueue.Empty:
-                    pass
+            while not stop_drain.is_set() or not src.chunk_status_queue.empty() or not dst_store.chunk_status_queue.empty():
+                for sq in (src.chunk_status_queue, dst_store.chunk_status_queue):
+                    try:
+                        status_records.append(sq.get(timeout=0.05))
+                    except pyqueue.Empty:
+                        pass
 
         def send(k):
             with socket.create_connection(("127.0.0.1", port)) as sock:
@@ -130,6 +129,10 @@ def main():
                 for idx, cr in enumerate(shares[k]):
                     with ready_cv:
                         ready_cv.wait_for(lambda: cr.chunk.chunk_id in ready or err_ev.is_set(), timeout=300)
+                    # what the reference's pre-registration POST does (gateway_operator.py:279-316), with the digest the
+                    # source operator computed riding along as a JSON-safe hex string
+                    dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+                    dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
                     header, payload = hip_sender.wire_payload(src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
                     header.to_socket(sock)
                     sock.sendall(payload)
@@ -139,6 +142,7 @@ def main():
         for cr in reqs:
             src.add_chunk_request(cr)
         op.start_workers()
+        dop.start_workers()
         drainer = threading.Thread(target=drain_status)
         drainer.start()
         threads = [threading.Thread(target=collect)] + [threading.Thread(target=send, args=(k,)) for k in range(args.connections) if shares[k]]
@@ -149,9 +153,17 @@ def main():
         n_rx = 0
         for _ in range(sum(1 for s in shares if s)):
             n_rx += len(done_q.get(timeout=300))
+        n_dec = 0
+        while n_dec < len(reqs) and not err_ev.is_set():                     # the destination operator has written every chunk file
+            try:
+                dq_out.q.get(timeout=0.2)
+                n_dec += 1
+            except pyqueue.Empty:
+                pass
         elapsed = time.perf_counter() - t0
         stop_drain.set()
         op.stop_workers()
+        dop.stop_workers()
         drainer.join()
         rx.join(60)
         assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"

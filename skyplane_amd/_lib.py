@@ -13,7 +13,7 @@ EXPORTS = (
     "skyhip_abi_version", "skyhip_create", "skyhip_destroy", "skyhip_frame_bound", "skyhip_process_batch", "skyhip_process_device",
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
-    "skyhip_host_alloc", "skyhip_host_free",
+    "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5",
 )
 
 
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     lib.skyhip_decompress_device.restype = C.c_int
     lib.skyhip_decompress_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.skyhip_decompress_batch.restype = C.c_int
+    lib.skyhip_decompress_batch_md5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.skyhip_decompress_batch_md5.restype = C.c_int
     lib.skyhip_decompress_ms.argtypes = [vp, C.c_int]
     lib.skyhip_decompress_ms.restype = C.c_double
     lib.skyhip_debug_prof.argtypes = [vp, vp]

@@ -594,8 +594,8 @@ int skyhip_decompress_device(skyhip_ctx* c, int n, const void* d_in, const uint6
     return sky_lz4d_run(&c->dec, c->s_lz4, n, d_in, in_off, in_len, d_out, out_off, out_cap, out_len, status, &c->dec_ms, c->hip_err, sizeof c->hip_err);
 }
 
-int skyhip_decompress_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
-                            size_t* out_len, int32_t* status) {
+int skyhip_decompress_batch_md5(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
+                                size_t* out_len, int32_t* status, uint8_t (*md5)[16]) {
     if (!c || n < 0) return SKYHIP_E_INVAL;
     if (n == 0) return SKYHIP_OK;
     if (!in || !in_len || !out || !out_cap || !out_len) return SKYHIP_E_INVAL;
@@ -604,21 +604,43 @@ int skyhip_decompress_batch(skyhip_ctx* c, int n, const uint8_t* const* in, cons
     uint64_t itot = 0, otot = 0;
     for (int i = 0; i < n; i++) {
         if (in_len[i] && !in[i]) return SKYHIP_E_INVAL;
+        if (out_cap[i] && !out[i]) return SKYHIP_E_INVAL;
+        if (md5 && out_cap[i] > c->max_chunk) return SKYHIP_E_TOOBIG;        // the digest kernel works on chunks of this context
         ioff[i] = itot; ilen[i] = in_len[i]; itot += (in_len[i] + 255) & ~(uint64_t)255;
         ooff[i] = otot; ocap[i] = out_cap[i]; otot += (out_cap[i] + 255) & ~(uint64_t)255;
     }
     HIPCHK(c, c->dec.d_stage_in.ensure(itot + 256)); HIPCHK(c, c->dec.d_stage_out.ensure(otot + 256));
-    for (int i = 0; i < n; i++)
-        if (in_len[i]) HIPCHK(c, hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_lz4));
-    int rc = sky_lz4d_run(&c->dec, c->s_lz4, n, c->dec.d_stage_in.p, ioff.data(), ilen.data(), c->dec.d_stage_out.p, ooff.data(), ocap.data(), olen.data(),
+    int rc = SKYHIP_OK;
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < n && he == hipSuccess; i++)
+        if (in_len[i]) he = hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_lz4);
+    if (he == hipSuccess) {
+        rc = sky_lz4d_run(&c->dec, c->s_lz4, n, c->dec.d_stage_in.p, ioff.data(), ilen.data(), c->dec.d_stage_out.p, ooff.data(), ocap.data(), olen.data(),
                           status, &c->dec_ms, c->hip_err, sizeof c->hip_err);
-    if (rc != SKYHIP_OK && rc != SKYHIP_E_FORMAT) return rc;
-    for (int i = 0; i < n; i++) {
-        out_len[i] = (size_t)olen[i];
-        if (olen[i]) HIPCHK(c, hipMemcpyAsync(out[i], c->dec.d_stage_out.p + ooff[i], olen[i], hipMemcpyDeviceToHost, c->s_lz4));
+        if (rc == SKYHIP_OK || rc == SKYHIP_E_FORMAT) {
+            // frames go home on the download stream while the digests of the decoded bytes are computed where they lie
+            for (int i = 0; i < n && he == hipSuccess; i++) {
+                out_len[i] = (size_t)olen[i];
+                if (olen[i]) he = hipMemcpyAsync(out[i], c->dec.d_stage_out.p + ooff[i], olen[i], hipMemcpyDeviceToHost, c->s_down);
+            }
+            if (md5 && he == hipSuccess) {
+                const int mrc = sky_process_impl(c, n, c->dec.d_stage_out.p, ooff.data(), olen.data(), nullptr, nullptr, nullptr, nullptr, md5, SKYHIP_F_MD5, nullptr);
+                if (mrc != SKYHIP_OK) rc = mrc;
+            }
+        }
     }
-    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    const hipError_t e1 = hipStreamSynchronize(c->s_lz4), e2 = hipStreamSynchronize(c->s_down);   // the caller's buffers are ours until here
+    if (he == hipSuccess) he = e1 != hipSuccess ? e1 : e2;
+    if (he != hipSuccess) {
+        snprintf(c->hip_err, sizeof(c->hip_err), "%s (decompress_batch)", hipGetErrorString(he));
+        return he == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP;
+    }
     return rc;
+}
+
+int skyhip_decompress_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
+                            size_t* out_len, int32_t* status) {
+    return skyhip_decompress_batch_md5(c, n, in, in_len, out, out_cap, out_len, status, nullptr);
 }
 
 double skyhip_decompress_ms(skyhip_ctx* c, int reset) {

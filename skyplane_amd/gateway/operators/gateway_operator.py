@@ -254,7 +254,8 @@ class GatewayHipCompress(GatewayOperator):
                     else:
                         retry.append(cr)
                 if retry:
-                    time.sleep(0.1)
+                    if len(retry) == len(batch):
+                        time.sleep(0.1)                # nothing could be done: wait like the reference does (:103-106)
                     for cr in retry:
                         self.input_queue.put(cr)
             except Exception:
@@ -268,3 +269,107 @@ class GatewayHipCompress(GatewayOperator):
             self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
             self._ctx = None
+
+
+class GatewayHipDecompress(GatewayHipCompress):
+    """op_type "gpu_decompress": the destination gateway's counterpart, in the place of the ``receive`` wait operator
+    (GatewayWaitReceiver, skyplane/gateway/operators/gateway_operator.py:125-149).
+
+    The reference's receiver decodes every chunk on the CPU inside recv_chunks (``lz4.frame.decompress``,
+    gateway_receiver.py:195-201) and GatewayWaitReceiver polls until ``<id>.chunk`` has its full length.  With the
+    receiver in deferred mode (hip_receiver.recv_chunks(decompress=None): the wire payload is left as
+    ``<id>.chunk.lz4f``) this operator waits for the payloads instead, decodes whatever has arrived in ONE batched
+    device call, checks what the reference checks and what it leaves as a todo --
+      * decoded length == chunk_length_bytes      (gateway_receiver.py:213-218, GatewayWaitReceiver's assert :143-145)
+      * MD5 of the decoded bytes == Chunk.md5_hash when the request carries one ("# todo check hash", :231); the digest
+        is computed on the GPU right after the decode --
+    writes ``<id>.chunk`` (temporary name + rename) and removes the payload.  A chunk whose payload has not arrived is
+    re-queued exactly like GatewayWaitReceiver returns False; a chunk that arrived uncompressed (``<id>.chunk`` already
+    complete) passes through.  A malformed frame or a digest mismatch raises -> error_queue + error_event, like the
+    reference's ChecksumMismatchException path.  Shares the batching worker loop, device binding and pinned staging of
+    GatewayHipCompress; there is no CPU fallback.
+    """
+
+    def __init__(self, *args, verify_md5: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.verify_md5 = verify_md5
+
+    @staticmethod
+    def _expected_digest(chunk_req: ChunkRequest) -> Optional[bytes]:
+        h = chunk_req.chunk.md5_hash
+        if h is None:
+            return None
+        if isinstance(h, str):
+            return bytes.fromhex(h)
+        return bytes(h)
+
+    def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
+        ctx = self._context()
+        oks = [False] * len(chunk_reqs)
+        self._last_metadata = [{} for _ in chunk_reqs]
+        todo = []                                      # indices whose payload is there
+        for i, cr in enumerate(chunk_reqs):
+            cid = cr.chunk.chunk_id
+            if self.chunk_store.get_compressed_file_path(cid).exists():
+                todo.append(i)
+                continue
+            raw = self.chunk_store.get_chunk_file_path(cid)
+            if raw.exists():                           # sent uncompressed: GatewayWaitReceiver's test (:132-147)
+                size = raw.stat().st_size
+                if size >= cr.chunk.chunk_length_bytes:
+                    assert size == cr.chunk.chunk_length_bytes, f"Downloaded chunk length does not match expected length: {size}, {cr.chunk.chunk_length_bytes}"
+                    oks[i] = True
+                    self._last_metadata[i] = {"uncompressed_size_bytes": size}
+        if not todo:
+            return oks
+        pinned = hasattr(ctx, "pinned_buffer")
+        paths = [self.chunk_store.get_compressed_file_path(chunk_reqs[i].chunk.chunk_id) for i in todo]
+        sizes = [p.stat().st_size for p in paths]
+        raw_lens = [int(chunk_reqs[i].chunk.chunk_length_bytes) for i in todo]
+        frames, into = [], None
+        if pinned:
+            arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
+            out = self._arena(ctx, "out", sum((r + 255) & ~255 for r in raw_lens))
+            into, pi, po = [], 0, 0
+            for p, s, r in zip(paths, sizes, raw_lens):
+                v = arena[pi:pi + s]
+                with open(p, "rb") as f:
+                    got, mv = 0, memoryview(v)
+                    while got < s:
+                        k = f.readinto(mv[got:])
+                        if not k:
+                            break
+                        got += k
+                assert got == s, f"payload {p.name} shrank while being read"
+                frames.append(v)
+                into.append(out[po:po + max(r, 1)])
+                pi += (s + 255) & ~255
+                po += (max(r, 1) + 255) & ~255
+        else:
+            frames = [p.read_bytes() for p in paths]
+        want = self.verify_md5 and any(self._expected_digest(chunk_reqs[i]) is not None for i in todo)
+        kwargs = {"want_md5": True} if want else {}
+        if into is not None:
+            kwargs["into"] = into
+        res = ctx.decompress_batch(frames, raw_lens, **kwargs)
+        datas, digests = res if want else (res, [None] * len(todo))
+        for i, p, data, dig, size in zip(todo, paths, datas, digests, sizes):
+            cr = chunk_reqs[i]
+            cid = cr.chunk.chunk_id
+            if len(data) != cr.chunk.chunk_length_bytes:
+                raise ValueError(f"[Gateway] chunk {cid}: {len(data)} bytes after decoding, expected {cr.chunk.chunk_length_bytes}")
+            exp = self._expected_digest(cr) if self.verify_md5 else None
+            if exp is not None and dig != exp:
+                raise ValueError(f"[Gateway] chunk {cid}: checksum mismatch, md5 {dig.hex()} != {exp.hex()}")
+            final = self.chunk_store.get_chunk_file_path(cid)
+            tmp = final.with_suffix(".dectmp")
+            with open(tmp, "wb") as f:
+                f.write(data)
+            os.replace(tmp, final)
+            p.unlink()
+            meta = {"compressed_size_bytes": size, "uncompressed_size_bytes": len(data)}
+            if dig is not None:
+                meta["md5_hex"] = dig.hex()
+            self._last_metadata[i] = meta
+            oks[i] = True
+        return oks

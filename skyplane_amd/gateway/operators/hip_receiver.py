@@ -7,8 +7,9 @@ raw_data_len (:204-218), stop when n_chunks_left_on_socket == 0 (:235-237).  End
 socket profiler queue are out of scope.  A size mismatch raises instead of retrying forever."""
 from __future__ import annotations
 
+import os
 import socket
-from typing import Callable, List
+from typing import Callable, List, Optional
 
 from skyplane_amd.chunk import WireProtocolHeader
 from skyplane_amd.gateway.chunk_store import ChunkStore
@@ -16,9 +17,12 @@ from skyplane_amd.gateway.chunk_store import ChunkStore
 MB = 1024 * 1024
 
 
-def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Callable[[bytes, int], bytes], recv_block_size: int = 4 * MB) -> List[str]:
+def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Optional[Callable[[bytes, int], bytes]], recv_block_size: int = 4 * MB) -> List[str]:
     """`decompress(frame, raw_len)` stands where lz4.frame.decompress stands in the reference, e.g.
-    ``lambda f, n: ctx.decompress_batch([f], [n])[0]`` with a SkyHipContext."""
+    ``lambda f, n: ctx.decompress_batch([f], [n])[0]`` with a SkyHipContext.
+    ``decompress=None`` defers the decode to the batching ``gpu_decompress`` operator (GatewayHipDecompress): a
+    compressed payload is left as ``<chunk_id>.chunk.lz4f`` (written under a temporary name and renamed, so its
+    existence means it is complete) and no ``<chunk_id>.chunk`` is written here."""
     received: List[str] = []
     while True:
         header = WireProtocolHeader.from_socket(conn)
@@ -29,6 +33,15 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Callab
             if n == 0:
                 raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
             got += n
+        if header.is_compressed and decompress is None:
+            final = chunk_store.get_compressed_file_path(header.chunk_id)
+            tmp = final.with_suffix(".rxtmp")
+            tmp.write_bytes(payload)
+            os.replace(tmp, final)
+            received.append(header.chunk_id)
+            if header.n_chunks_left_on_socket == 0:
+                return received
+            continue
         data = decompress(bytes(payload), header.raw_data_len) if header.is_compressed else bytes(payload)
         if len(data) != header.raw_data_len:
             raise ValueError(f"[Gateway] chunk {header.chunk_id}: {len(data)} bytes after decoding, header says {header.raw_data_len}")

@@ -149,24 +149,31 @@ class SkyHipContext:
         return out_len, md5
 
     # -- decompression (destination gateway: lz4.frame.decompress at gateway_receiver.py:195-201) ----------
-    def decompress_batch(self, frames: Sequence, raw_lens: Sequence[int]):
-        """frames[i] decodes into at most raw_lens[i] bytes (WireProtocolHeader.raw_data_len). Returns list of bytes;
-        raises SkyHipError(-8) if any frame is malformed (like lz4.frame.decompress raising)."""
+    def decompress_batch(self, frames: Sequence, raw_lens: Sequence[int], want_md5: bool = False, into: Optional[Sequence[np.ndarray]] = None):
+        """frames[i] decodes into at most raw_lens[i] bytes (WireProtocolHeader.raw_data_len). Returns a list of bytes
+        (views of `into` when given: uint8 arrays of >= raw_lens[i] bytes, ideally pinned); with want_md5 also the
+        digests of the decoded bytes, computed on the device: (outs, digests).
+        Raises SkyHipError(-8) if any frame is malformed (like lz4.frame.decompress raising)."""
         n = len(frames)
         if n == 0:
-            return []
+            return ([], []) if want_md5 else []
         arrs = [np.frombuffer(f, np.uint8) if not isinstance(f, np.ndarray) else np.ascontiguousarray(f.reshape(-1).view(np.uint8)) for f in frames]
-        outs = [np.empty(max(int(r), 1), np.uint8) for r in raw_lens]
+        outs = list(into) if into is not None else [np.empty(max(int(r), 1), np.uint8) for r in raw_lens]
+        if len(outs) != n or any(o.size < int(r) for o, r in zip(outs, raw_lens)):
+            raise ValueError("into: one uint8 array of at least raw_lens[i] bytes per frame")
         in_ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
         in_len = (C.c_size_t * n)(*[a.size for a in arrs])
         out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         out_cap = (C.c_size_t * n)(*[int(r) for r in raw_lens])
         out_len = (C.c_size_t * n)()
         status = (C.c_int32 * n)()
-        rc = self._lib.skyhip_decompress_batch(self._h, n, in_ptrs, in_len, out_ptrs, out_cap, out_len, status)
+        md5 = np.zeros((n, 16), np.uint8) if want_md5 else None
+        rc = self._lib.skyhip_decompress_batch_md5(self._h, n, in_ptrs, in_len, out_ptrs, out_cap, out_len, status,
+                                                   md5.ctypes.data if md5 is not None else None)
         self.last_decode_status = list(status)
         self._check(rc)
-        return [outs[i][: out_len[i]].tobytes() for i in range(n)]
+        res = [outs[i][: out_len[i]] if into is not None else outs[i][: out_len[i]].tobytes() for i in range(n)]
+        return (res, [md5[i].tobytes() for i in range(n)]) if want_md5 else res
 
     def decompress_device(self, d_in: int, in_off, in_len, d_out: int, out_off, out_cap):
         n = int(len(in_off))

@@ -102,3 +102,29 @@ def test_chunks_ending_in_long_runs(ctx):
               synth.gen_class("random", 100_000, rng).tobytes() + b"\x07" * 70_000]
     for c, r in zip(chunks, ctx.process_batch(chunks, flags=3)):
         assert ref.lz4f_decompress(r.frame, len(c)) == c and r.md5 == hashlib.md5(c).digest()
+
+
+def test_decode_with_device_digests_and_pinned_targets(ctx):
+    """skyhip_decompress_batch_md5: the digest of the DECODED bytes is computed on the device right after the decode
+    (receiver-side check, gateway_receiver.py:231 "todo check hash"); pinned targets receive the bytes in place."""
+    import hashlib
+    rng = synth.rng_for(55)
+    chunks = [synth.gen_class(synth.CLASSES[i % len(synth.CLASSES)], s, rng).tobytes() for i, s in enumerate([1 << 20, 70_001, 13, 1, 65536, 3 << 20])]
+    chunks.append(b"")
+    frames = [ref.lz4f_compress(c) if i % 2 else ctx.process_batch([c], flags=1)[0].frame for i, c in enumerate(chunks)]
+    outs, digs = ctx.decompress_batch(frames, [len(c) for c in chunks], want_md5=True)
+    assert outs == chunks and digs == [hashlib.md5(c).digest() for c in chunks]
+    arena_in = ctx.pinned_buffer(sum((len(f) + 255) & ~255 for f in frames) + 256)
+    arena_out = ctx.pinned_buffer(sum((len(c) + 255) & ~255 for c in chunks) + 256)
+    vin, vout, pi, po = [], [], 0, 0
+    for f, c in zip(frames, chunks):
+        v = arena_in[pi:pi + len(f)]
+        v[:] = np.frombuffer(f, np.uint8)
+        vin.append(v)
+        vout.append(arena_out[po:po + max(len(c), 1)])
+        pi += (len(f) + 255) & ~255
+        po += (max(len(c), 1) + 255) & ~255
+    outs2, digs2 = ctx.decompress_batch(vin, [len(c) for c in chunks], want_md5=True, into=vout)
+    assert [bytes(o) for o in outs2] == chunks and digs2 == digs
+    assert [bytes(o) for o in ctx.decompress_batch(vin, [len(c) for c in chunks], into=vout)] == chunks
+    ctx.release_pinned(arena_in); ctx.release_pinned(arena_out)

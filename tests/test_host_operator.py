@@ -81,6 +81,18 @@ def _arena_factory(dev, mc, mb):
     return _ArenaContext(dev, mc, mb)
 
 
+class _DecodeContext(_OracleContext):
+    """Double for the destination side: SkyHipContext.decompress_batch over liblz4 + hashlib."""
+
+    def decompress_batch(self, frames, raw_lens, want_md5=False, into=None):
+        outs = [ref.lz4f_decompress(bytes(f), n) for f, n in zip(frames, raw_lens)]
+        return (outs, [hashlib.md5(o).digest() for o in outs]) if want_md5 else outs
+
+
+def _decode_factory(dev, mc, mb):
+    return _DecodeContext(dev, mc, mb)
+
+
 def _make_store(tmp_path, n, size=70_000):
     store = ChunkStore(tmp_path / "chunks")
     q_in, q_out = GatewayQueue(), GatewayQueue()
@@ -175,6 +187,71 @@ def test_operator_zero_copy_staging_path(tmp_path, monkeypatch):
     op.worker_exit(0)
 
 
+def test_decompress_operator_waits_decodes_verifies(tmp_path, monkeypatch):
+    """Destination side: the receiver in deferred mode leaves wire payloads as sidecars, the
+    gpu_decompress operator waits for them like GatewayWaitReceiver waits for chunk files, decodes in batches, checks
+    length and digest, writes <id>.chunk."""
+    import socket
+    import threading
+    from skyplane_amd.gateway.operators import hip_receiver
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    n = 9
+    src, _, _, reqs = _make_store(tmp_path / "src", n, size=50_000)
+    for i, (cr, data) in enumerate(reqs):                                     # what gpu_compress leaves on the source side
+        if i != 4:                                                            # chunk 4 travels uncompressed
+            src.get_compressed_file_path(cr.chunk.chunk_id).write_bytes(ref.lz4f_compress_port(data))
+        cr.chunk.md5_hash = [hashlib.md5(data).digest(), hashlib.md5(data).hexdigest(), None][i % 3]
+    dst = ChunkStore(tmp_path / "dst" / "chunks")
+    q_in, q_out = GatewayQueue(), GatewayQueue()
+    dst.add_partition("0", q_in)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipDecompress("gpu_decompress_0", "local:dst", q_in, q_out, err_ev, err_q, dst, n_processes=1, max_batch=4, device_ids=[0],
+                              context_factory=_decode_factory)
+    for cr, _ in reqs:
+        dst.add_chunk_request(cr)                                             # registered before anything has arrived
+    op.start_workers()
+    time.sleep(0.3)
+    assert q_out.q.empty()                                                    # nothing decoded out of thin air
+    a, b = socket.socketpair()
+    rx = threading.Thread(target=lambda: hip_receiver.recv_chunks(b, dst, None))
+    rx.start()
+    hip_sender.send_chunks(a, src, [cr for cr, _ in reqs])
+    rx.join(20)
+    done = _drain(q_out.q, n)
+    op.stop_workers()
+    a.close(); b.close()
+    assert not err_ev.is_set(), err_q.get() if not err_q.empty() else ""
+    assert sorted(c.chunk.chunk_id for c in done) == sorted(cr.chunk.chunk_id for cr, _ in reqs)
+    for cr, data in reqs:
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == data
+        assert not dst.get_compressed_file_path(cr.chunk.chunk_id).exists()   # payload consumed
+    recs = [r for r in _drain(dst.chunk_status_queue, 200, timeout=2) if r["state"] == "complete"]
+    assert len(recs) == n and sum("md5_hex" in r for r in recs) >= 5
+
+
+def test_decompress_operator_checksum_mismatch_is_an_error(tmp_path, monkeypatch):
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    store, q_in, q_out, reqs = _make_store(tmp_path, 2, size=20_000)
+    for cr, data in reqs:
+        store.get_compressed_file_path(cr.chunk.chunk_id).write_bytes(ref.lz4f_compress(data))
+        store.get_chunk_file_path(cr.chunk.chunk_id).unlink()
+        cr.chunk.md5_hash = hashlib.md5(data).digest()
+    reqs[1][0].chunk.md5_hash = hashlib.md5(b"something else").digest()
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipDecompress("gpu_decompress_0", "r", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=8, device_ids=[0], context_factory=_decode_factory)
+    for cr, _ in reqs:
+        store.add_chunk_request(cr)
+    op.start_workers()
+    assert err_ev.wait(20)
+    tb = err_q.get(timeout=5)
+    op.stop_workers()
+    assert "checksum mismatch" in tb
+
+
 def test_operator_error_path_matches_reference(tmp_path, monkeypatch):
     monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
     store, q_in, q_out, reqs = _make_store(tmp_path, 2)
@@ -247,6 +324,10 @@ def test_program_node_and_registration(tmp_path):
     assert isinstance(op, GatewayHipCompress) and op.n_processes == 8 and op.max_batch == 16 and op.cdc
     with pytest.raises(ValueError):
         gateway_program.create_operator({"op_type": "nope"}, "h", "r", None, None, None, None, store)
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
+    d2 = gateway_program.GatewayGpuDecompress(num_workers=2, max_batch=64, verify_md5=False).to_dict()
+    op2 = gateway_program.create_operator(d2, "gpu_decompress_n2", "r", GatewayQueue(), GatewayQueue(), Event(), Queue(), store)
+    assert isinstance(op2, GatewayHipDecompress) and op2.n_processes == 2 and op2.max_batch == 64 and op2.verify_md5 is False
 
 
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
@@ -254,7 +335,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
 
     lib = _lib.load()
     header = (ROOT / "include" / "skyhip.h").read_text()
-    declared = set(re.findall(r"\b(skyhip_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(skyhip_[a-z0-9_]+)\s*\(", header))
     assert declared and declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
