@@ -9,10 +9,9 @@ from pathlib import Path
 from typing import Dict, Optional
 
 from skyplane_amd.chunk import ChunkRequest, ChunkState
+from skyplane_amd.gateway import sidecar
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
-
-SIDECAR_SUFFIX = ".lz4f"   # <chunk_id>.chunk.lz4f : the pre-compressed frame the sender ships
-DIGEST_SUFFIX = ".md5"     # <chunk_id>.chunk.md5  : hex digest side channel (Chunk.md5_hash as bytes breaks JSON)
+from skyplane_amd.gateway.sidecar import DIGEST_SUFFIX, SIDECAR_SUFFIX   # <id>.chunk.lz4f / <id>.chunk.md5
 
 
 class ChunkStore:
@@ -53,7 +52,7 @@ class ChunkStore:
 
     # -- additions used by the GPU stage and the cooperating sender --------------------------------------
     def get_compressed_file_path(self, chunk_id: str) -> Path:
-        return self.chunk_dir / f"{chunk_id}.chunk{SIDECAR_SUFFIX}"
+        return sidecar.compressed_path(self, chunk_id)
 
     def get_digest_file_path(self, chunk_id: str) -> Path:
-        return self.chunk_dir / f"{chunk_id}.chunk{DIGEST_SUFFIX}"
+        return sidecar.digest_path(self, chunk_id)

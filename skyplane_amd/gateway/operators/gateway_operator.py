@@ -28,6 +28,7 @@ from multiprocessing import Event, Process, Queue
 from typing import Callable, List, Optional
 
 from skyplane_amd.chunk import ChunkRequest, ChunkState
+from skyplane_amd.gateway import sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
 
@@ -213,13 +214,13 @@ class GatewayHipCompress(GatewayOperator):
         self._last_metadata = []
         for cr, data, res in zip(chunk_reqs, datas, results):
             cid = cr.chunk.chunk_id
-            tmp = self.chunk_store.get_compressed_file_path(cid).with_suffix(".tmp")
+            tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
             with open(tmp, "wb") as f:
                 f.write(res.frame)
-            os.replace(tmp, self.chunk_store.get_compressed_file_path(cid))   # the sender never sees a partial frame
+            os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
             meta = {"compressed_size_bytes": len(res.frame), "uncompressed_size_bytes": len(data)}
             if res.md5 is not None:
-                self.chunk_store.get_digest_file_path(cid).write_text(res.md5.hex())
+                sidecar.digest_path(self.chunk_store, cid).write_text(res.md5.hex())
                 meta["md5_hex"] = res.md5.hex()
             if res.cuts is not None:
                 meta["cdc_segments"] = int(len(res.cuts))
@@ -310,7 +311,7 @@ class GatewayHipDecompress(GatewayHipCompress):
         todo = []                                      # indices whose payload is there
         for i, cr in enumerate(chunk_reqs):
             cid = cr.chunk.chunk_id
-            if self.chunk_store.get_compressed_file_path(cid).exists():
+            if sidecar.compressed_path(self.chunk_store, cid).exists():
                 todo.append(i)
                 continue
             raw = self.chunk_store.get_chunk_file_path(cid)
@@ -323,7 +324,7 @@ class GatewayHipDecompress(GatewayHipCompress):
         if not todo:
             return oks
         pinned = hasattr(ctx, "pinned_buffer")
-        paths = [self.chunk_store.get_compressed_file_path(chunk_reqs[i].chunk.chunk_id) for i in todo]
+        paths = [sidecar.compressed_path(self.chunk_store, chunk_reqs[i].chunk.chunk_id) for i in todo]
         sizes = [p.stat().st_size for p in paths]
         raw_lens = [int(chunk_reqs[i].chunk.chunk_length_bytes) for i in todo]
         frames, into = [], None

@@ -12,6 +12,7 @@ import socket
 from typing import Callable, List, Optional
 
 from skyplane_amd.chunk import WireProtocolHeader
+from skyplane_amd.gateway import sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 
 MB = 1024 * 1024
@@ -34,7 +35,7 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
                 raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
             got += n
         if header.is_compressed and decompress is None:
-            final = chunk_store.get_compressed_file_path(header.chunk_id)
+            final = sidecar.compressed_path(chunk_store, header.chunk_id)
             tmp = final.with_suffix(".rxtmp")
             tmp.write_bytes(payload)
             os.replace(tmp, final)

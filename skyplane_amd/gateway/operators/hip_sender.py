@@ -8,14 +8,15 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
+from skyplane_amd.gateway import sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 
 
 def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int) -> Tuple[WireProtocolHeader, bytes]:
     chunk = chunk_req.chunk
-    sidecar = chunk_store.get_compressed_file_path(chunk.chunk_id)
-    if sidecar.exists():
-        data = sidecar.read_bytes()
+    frame_path = sidecar.compressed_path(chunk_store, chunk.chunk_id)
+    if frame_path.exists():
+        data = frame_path.read_bytes()
         header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=len(data),
                                       raw_wire_length=chunk.chunk_length_bytes, is_compressed=True)
         return header, data
@@ -39,13 +40,13 @@ def send_chunks(sock, chunk_store: ChunkStore, chunk_reqs) -> int:
 
 def chunk_digest(chunk_store: ChunkStore, chunk_id: str) -> Optional[bytes]:
     """The 16-byte digest Chunk.md5_hash is declared to carry (chunk.py:21), read from the side channel."""
-    p = chunk_store.get_digest_file_path(chunk_id)
+    p = sidecar.digest_path(chunk_store, chunk_id)
     return bytes.fromhex(p.read_text().strip()) if p.exists() else None
 
 
 def cleanup_sidecars(chunk_store: ChunkStore, chunk_id: str):
     """gateway_daemon_api.py:125-127 unlinks only <id>.chunk; whoever completes the chunk removes the sidecars."""
-    for p in (chunk_store.get_compressed_file_path(chunk_id), chunk_store.get_digest_file_path(chunk_id)):
+    for p in (sidecar.compressed_path(chunk_store, chunk_id), sidecar.digest_path(chunk_store, chunk_id)):
         try:
             p.unlink()
         except FileNotFoundError:

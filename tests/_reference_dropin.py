@@ -1,0 +1,205 @@
+"""Drop-in proof with the reference's own classes (build container only; run by tests/test_reference_interop.py).
+
+1. This repo's operator module is imported with its three host mirrors ALIASED to the reference's modules
+   (skyplane.chunk, skyplane.gateway.chunk_store, skyplane.gateway.gateway_queue) -- what INTEGRATION.md section 3
+   tells a maintainer to do -- and GatewayHipCompress runs, in its forked worker, on the reference's unmodified
+   ChunkStore / GatewayQueue / ChunkRequest objects.  The device context is the shipping kernel source under the CPU
+   emulator (no GPU here).
+2. The reference's GatewaySender is loaded from /root/reference at run time with INTEGRATION.md section 6's edits applied
+   to the source text IN MEMORY (nothing is copied into the repo), `lz4.frame.compress` booby-trapped, and streams the
+   operator's frames to the reference's own GatewayReceiver, which must reproduce every chunk.
+TEST INFRASTRUCTURE ONLY.
+"""
+import hashlib
+import importlib
+import json
+import queue as pyqueue
+import socket
+import sys
+import tempfile
+import threading
+import time
+import types
+import uuid
+from multiprocessing import Event, Queue
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import refshim  # noqa: E402
+
+scratch = Path(tempfile.mkdtemp(prefix="sky_dropin_"))
+refshim.install(scratch / "shim")
+
+import skyplane.chunk as ref_chunk  # noqa: E402
+import skyplane.gateway.chunk_store as ref_chunk_store  # noqa: E402
+import skyplane.gateway.gateway_queue as ref_queue  # noqa: E402
+from skyplane.gateway.operators.gateway_receiver import GatewayReceiver as RefGatewayReceiver  # noqa: E402
+
+# --- the operator's imports pointed at the reference's modules -----------------------------
+sys.modules["skyplane_amd.chunk"] = ref_chunk
+sys.modules["skyplane_amd.gateway.chunk_store"] = ref_chunk_store
+sys.modules["skyplane_amd.gateway.gateway_queue"] = ref_queue
+import skyplane_amd.gateway  # noqa: E402
+
+skyplane_amd.gateway.chunk_store = ref_chunk_store
+skyplane_amd.gateway.gateway_queue = ref_queue
+from skyplane_amd import synth  # noqa: E402
+from skyplane_amd.gateway import sidecar  # noqa: E402
+from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress  # noqa: E402
+from skyplane_amd.hip_ops import ChunkResult  # noqa: E402  (dataclass only; the library is not loaded)
+from tests.emu import emulib  # noqa: E402
+
+
+class EmuContext:
+    """SkyHipContext.process_batch over the shipping kernel source run by the CPU SIMT emulator."""
+
+    def __init__(self, device_id, max_chunk_bytes, max_batch):
+        pass
+
+    def process_batch(self, chunks, flags=3):
+        frames, md5s, _ = emulib.process([bytes(c) for c in chunks], flags=flags)
+        return [ChunkResult(frame=f, md5=m if flags & 2 else None) for f, m in zip(frames, md5s)]
+
+    def close(self):
+        pass
+
+
+def _patched_sender_module():
+    """The reference's gateway_operator.py + INTEGRATION.md section 6, applied to the text in memory."""
+    path = refshim.REFERENCE / "skyplane" / "gateway" / "operators" / "gateway_operator.py"
+    src = path.read_text()
+    edits = [
+        # read the pre-compressed sidecar when gpu_compress left one
+        ('            with open(chunk_file_path, "rb") as f:\n                data = f.read()\n',
+         '            lz4f_path = chunk_file_path.with_name(chunk_file_path.name + ".lz4f")\n'
+         '            precompressed = lz4f_path.exists()                      # produced by gpu_compress\n'
+         '            with open(lz4f_path if precompressed else chunk_file_path, "rb") as f:\n                data = f.read()\n'),
+        ('            assert len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size',
+         '            assert precompressed or len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size'),
+        ('            raw_wire_length = wire_length\n',
+         '            raw_wire_length = chunk.chunk_length_bytes if precompressed else wire_length\n'),
+        ('            if self.use_compression:\n                data = lz4.frame.compress(data)\n',
+         '            if precompressed:\n                compressed_length = wire_length\n'
+         '            elif self.use_compression:\n                data = lz4.frame.compress(data)\n'),
+    ]
+    for old, new in edits:
+        assert src.count(old) == 1, f"INTEGRATION.md patch anchor not found exactly once: {old!r}"
+        src = src.replace(old, new)
+    mod = types.ModuleType("skyplane.gateway.operators.gateway_operator_gpu_patch")
+    mod.__file__ = str(path)
+    exec(compile(src, str(path), "exec"), mod.__dict__)
+    return mod
+
+
+class _Reply:
+    status = 200
+
+    def __init__(self, body):
+        self.data = json.dumps(body).encode()
+
+
+class _ControlPlaneStub:
+    def request(self, method, url, body=None, headers=None):
+        assert method == "POST" and url.endswith("/api/v1/chunk_requests"), (method, url)
+        return _Reply({"status": "ok", "n_added": len(json.loads(body))})
+
+
+def main():
+    datas = {}
+    for i, cls in enumerate(synth.CLASSES):
+        datas[uuid.uuid4().hex] = synth.gen_class(cls, 120_000 + 777 * i, synth.rng_for(91, i)).tobytes()
+    datas[uuid.uuid4().hex] = bytes(70_000)
+    datas[uuid.uuid4().hex] = b"tiny"
+
+    # ---- 1. the operator on the reference's objects ------------------------------------------------------------
+    src = ref_chunk_store.ChunkStore(str(scratch / "src_chunks"))
+    q_in, q_out = ref_queue.GatewayQueue(), ref_queue.GatewayQueue()
+    src.add_partition("0", q_in)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "local:src", q_in, q_out, err_ev, err_q, src, n_processes=1, max_batch=4, device_ids=[0],
+                            context_factory=lambda d, mc, mb: EmuContext(d, mc, mb))
+    reqs = []
+    for cid, d in datas.items():
+        src.get_chunk_file_path(cid).write_bytes(d)
+        cr = ref_chunk.ChunkRequest(chunk=ref_chunk.Chunk(src_key=cid, dest_key=cid, chunk_id=cid, chunk_length_bytes=len(d), partition_id="0"))
+        reqs.append(cr)
+        assert src.add_chunk_request(cr)[1]
+    stop = threading.Event()
+    records = []
+
+    def drain():
+        while not stop.is_set():
+            try:
+                records.append(src.chunk_status_queue.get(timeout=0.05))
+            except pyqueue.Empty:
+                pass
+
+    threading.Thread(target=drain, daemon=True).start()
+    op.start_workers()
+    done, t0 = [], time.time()
+    while len(done) < len(reqs) and time.time() - t0 < 120 and not err_ev.is_set():
+        try:
+            done.append(q_out.get_nowait())
+        except pyqueue.Empty:
+            time.sleep(0.01)
+    op.stop_workers()
+    assert not err_ev.is_set(), err_q.get() if not err_q.empty() else ""
+    assert sorted(c.chunk.chunk_id for c in done) == sorted(datas)
+    time.sleep(0.2)
+    stop.set()
+    comp = [r for r in records if r["state"] == "complete"]
+    assert len(comp) == len(datas) and all(r["compressed_size_bytes"] > 0 and r["uncompressed_size_bytes"] == len(datas[r["chunk_id"]]) for r in comp)
+    for cid, d in datas.items():
+        assert src.get_chunk_file_path(cid).read_bytes() == d                                   # raw chunk untouched (:352 still holds)
+        assert sidecar.digest_path(src, cid).read_text() == hashlib.md5(d).hexdigest()
+
+    # ---- 2. reference sender (+ section 6 patch) -> reference receiver ---------------------------------------
+    patched = _patched_sender_module()
+
+    def _no_cpu_compress(data, **kw):
+        raise AssertionError("the sender compressed on the CPU although gpu_compress had left a frame")
+
+    patched.lz4 = types.SimpleNamespace(frame=types.SimpleNamespace(compress=_no_cpu_compress))
+    dst = ref_chunk_store.ChunkStore(str(scratch / "dst_chunks"))
+    r_err_ev, r_err_q = Event(), Queue()
+    receiver = RefGatewayReceiver("recv", "local:dst", dst, r_err_ev, r_err_q, use_tls=False, use_compression=True)
+    port = receiver.start_server()
+    sender = patched.GatewaySender("send", "local:src", ref_queue.GatewayQueue(), ref_queue.GatewayQueue(), Event(), Queue(), src, ip_addr="127.0.0.1",
+                                   use_tls=False, use_compression=True, n_processes=1)
+    sender.worker_id = 0
+    sender.http_pool = _ControlPlaneStub()
+    sock = socket.create_connection(("127.0.0.1", port))
+    sender.destination_ports["127.0.0.1"] = port
+    sender.destination_sockets["127.0.0.1"] = sock
+    wire = 0
+    for cr in reqs:
+        assert sender.process(cr, "127.0.0.1") is True
+        wire += sidecar.compressed_path(src, cr.chunk.chunk_id).stat().st_size
+    last = dst.get_chunk_file_path(reqs[-1].chunk.chunk_id)
+    t0 = time.time()
+    while time.time() - t0 < 60 and not (last.exists() and last.stat().st_size == len(datas[reqs[-1].chunk.chunk_id])):
+        time.sleep(0.02)
+    sock.close()
+    for p in receiver.server_processes:
+        p.terminate()
+        p.join(10)
+    assert not r_err_ev.is_set()
+    for cid, d in datas.items():
+        assert dst.get_chunk_file_path(cid).read_bytes() == d, cid
+    # one chunk without a sidecar still takes the reference's own path (and its CPU compressor)
+    cid = uuid.uuid4().hex
+    src.get_chunk_file_path(cid).write_bytes(b"no sidecar" * 100)
+    cr = ref_chunk.ChunkRequest(chunk=ref_chunk.Chunk(src_key=cid, dest_key=cid, chunk_id=cid, chunk_length_bytes=1000, partition_id="0"))
+    try:
+        sender.destination_sockets["127.0.0.1"] = socket.socket()
+        sender.process(cr, "127.0.0.1")
+        raise SystemExit("expected the booby-trapped CPU compressor to be reached")
+    except AssertionError as e:
+        assert "compressed on the CPU" in str(e)
+    print(f"OK dropin chunks={len(datas)} wire_bytes={wire} raw_bytes={sum(map(len, datas.values()))}")
+
+
+if __name__ == "__main__":
+    main()
