@@ -16,7 +16,8 @@ pytestmark = pytest.mark.skipif(not refshim.available(), reason="reference tree 
 def test_operator_is_a_drop_in_for_the_reference_classes():
     """INTEGRATION.md sections 3 and 6, executed: the operator module on the reference's own ChunkStore / GatewayQueue /
     ChunkRequest, then the reference's GatewaySender with the documented edits applied in memory, streaming the
-    operator's frames to the reference's GatewayReceiver (tests/_reference_dropin.py)."""
+    operator's frames to the reference's GatewayReceiver; then the destination side: the reference's GatewayReceiver with
+    section 6b's deferred-decode branch feeding GatewayHipDecompress on reference objects (tests/_reference_dropin.py)."""
     from tests.emu import emulib
     emulib.lib()
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "_reference_dropin.py")], capture_output=True, text=True, timeout=600)
