@@ -186,8 +186,11 @@ if __name__ == "__main__":
     import io
     import signal
 
-    os.setpgrp()      # own process group: the reference's receiver servers spin forever on a closed socket
+    try:
+        os.setpgrp()  # own process group: the reference's receiver servers spin forever on a closed socket
                       # (WireProtocolHeader.from_socket has no EOF check) and are reaped as a group at the end
+    except PermissionError:
+        pass
 
     datas = make_data(args.chunks)
     res = {"what": "reference gateway sender->receiver over loopback, CPU only (BASELINE configs[0] shape)", "data": args.data, "chunk_bytes": CB,

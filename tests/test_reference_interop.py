@@ -32,3 +32,34 @@ def test_interop_with_reference_gateway(scenario):
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "_reference_interop.py"), scenario], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, f"{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
     assert f"OK {scenario}" in p.stdout
+
+
+def _run_daemon_harness(*args, timeout=240):
+    """oracle/ref_daemon.py forks two reference daemons (which fork busy-spinning workers): own session, and the
+    whole group is killed if it overstays."""
+    import json
+    import os
+    import signal
+
+    p = subprocess.Popen([sys.executable, str(ROOT / "oracle" / "ref_daemon.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail(f"daemon harness timed out\n{err[-3000:]}")
+    assert p.returncode == 0, f"{out[-2000:]}\n{err[-4000:]}"
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def test_reference_daemons_plain_and_with_gpu_compress_operator():
+    """Two REAL GatewayDaemons on localhost (Flask API, forked operators, receiver servers: all from /root/reference).
+    First the reference's own DAG (BASELINE configs[0] shape, small), then the same with `gpu_compress` registered through
+    INTEGRATION.md section 5's branch and section 6's sender edits -- the CPU compressor is booby-trapped in that run."""
+    from tests.emu import emulib
+    emulib.lib()
+    r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "512", "--connections", "2")
+    assert r["verified"] and r["chunks"] == 6 and not r["gpu_op"]
+    r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "128", "--connections", "2", "--gpu-op")
+    assert r["verified"] and r["gpu_op"] and r["gpu_compress_chunks"] == 6
