@@ -57,6 +57,15 @@ def test_reference_daemons_plain_and_with_gpu_compress_operator():
     """Two REAL GatewayDaemons on localhost (Flask API, forked operators, receiver servers: all from /root/reference).
     First the reference's own DAG (BASELINE configs[0] shape, small), then the same with `gpu_compress` registered through
     INTEGRATION.md section 5's branch and section 6's sender edits -- the CPU compressor is booby-trapped in that run."""
+    import socket
+
+    for port in (8080, 8081, 8083):          # the reference hard-codes 8080 (sender -> API) and 8081 (API); 8083 is the harness's
+        with socket.socket() as probe:
+            probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                probe.bind(("127.0.0.1", port))
+            except OSError:
+                pytest.skip(f"port {port} is taken on this machine")
     from tests.emu import emulib
     emulib.lib()
     r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "512", "--connections", "2")
