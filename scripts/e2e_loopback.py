@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--chunk-mib", type=int, default=8)
     ap.add_argument("--connections", type=int, default=4)
     ap.add_argument("--max-batch", type=int, default=32)
+    ap.add_argument("--workers", type=int, default=1, help="forked operator workers per side (each with its own HIP context on GPU 0)")
     args = ap.parse_args()
     size = args.chunk_mib << 20
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
@@ -89,8 +90,8 @@ def main():
         rx.start()
         port = port_q.get(timeout=120)
         err_ev, err_q = Event(), Queue()
-        op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=1, max_batch=args.max_batch, max_chunk_bytes=size, device_ids=[0])
-        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1, max_batch=args.max_batch,
+        op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=args.workers, max_batch=args.max_batch, max_chunk_bytes=size, device_ids=[0])
+        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=args.workers, max_batch=args.max_batch,
                                    max_chunk_bytes=size, device_ids=[0])
         # static split of the chunk set over the connections, like the reference's per-connection chunk lists
         shares = [reqs[k::args.connections] for k in range(args.connections)]
@@ -172,7 +173,7 @@ def main():
             got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
             assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
         raw = len(reqs) * size
-        print(json.dumps({"e2e": "loopback", "chunks": len(reqs), "chunk_mib": args.chunk_mib, "connections": args.connections,
+        print(json.dumps({"e2e": "loopback", "chunks": len(reqs), "chunk_mib": args.chunk_mib, "connections": args.connections, "workers": args.workers,
                           "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 2), "raw_GiB": round(raw / 2**30, 2), "wire_ratio": round(raw / sum(wire), 3),
                           "seconds": round(elapsed, 2), "status_records": len(status_records), "verified": True}))
 
