@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Steady-state variant of scripts/e2e_loopback.py: same topology
+
+    chunk files -> gpu_compress operator -> sender threads -> K loopback TCP connections -> deferred receiver
+                -> gpu_decompress operator (decode + on-device MD5 check) -> chunk files
+
+but the clock starts only after one warm-up chunk per connection has travelled the whole path, i.e. after every forked
+worker has created its device context, grown its pinned arenas and every TCP connection is up -- what a transfer of
+minutes amortises anyway.  (e2e_loopback.py times a cold start and is the one the GPU test suite runs.)
+
+--context emu runs both operators on the shipping kernel source under the CPU emulator (tests/emu): that is how this
+script is tested without a GPU (tests/test_host_operator.py); use small --chunk-kib with it.
+"""
+import argparse
+import dataclasses
+import hashlib
+import json
+import os
+import queue as pyqueue
+import socket
+import sys
+import tempfile
+import threading
+import time
+import uuid
+from multiprocessing import Event, Process, Queue
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "scripts"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from e2e_loopback import receiver_main  # noqa: E402  (the deferred receiver process)
+from skyplane_amd import synth  # noqa: E402
+from skyplane_amd.chunk import Chunk, ChunkRequest  # noqa: E402
+from skyplane_amd.gateway.chunk_store import ChunkStore  # noqa: E402
+from skyplane_amd.gateway.gateway_queue import GatewayQueue  # noqa: E402
+from skyplane_amd.gateway.operators import hip_sender  # noqa: E402
+from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress, GatewayHipDecompress  # noqa: E402
+
+
+def emu_context_factory(device_id, max_chunk_bytes, max_batch):
+    """Device stand-in for machines without a GPU: the shipping kernels' source run by the CPU SIMT emulator."""
+    from skyplane_amd.hip_ops import ChunkResult
+    from tests.emu import emulib
+
+    class EmuContext:
+        def process_batch(self, chunks, flags=3):
+            frames, md5s, _ = emulib.process([bytes(c) for c in chunks], flags=flags)
+            return [ChunkResult(frame=f, md5=m if flags & 2 else None) for f, m in zip(frames, md5s)]
+
+        def decompress_batch(self, frames, raw_lens, want_md5=False, into=None):
+            rc, outs, status = emulib.decompress([bytes(f) for f in frames], [int(r) for r in raw_lens])
+            if rc != 0:
+                raise ValueError(f"frame rejected: {status}")
+            return (outs, emulib.process(outs, flags=2)[1]) if want_md5 else outs
+
+        def close(self):
+            pass
+
+    return EmuContext()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=256)
+    ap.add_argument("--chunk-kib", type=int, default=8192)
+    ap.add_argument("--connections", type=int, default=8)
+    ap.add_argument("--max-batch", type=int, default=64)
+    ap.add_argument("--workers", type=int, default=1)
+    ap.add_argument("--context", choices=["hip", "emu"], default="hip")
+    a = ap.parse_args()
+    size = a.chunk_kib << 10
+    factory = emu_context_factory if a.context == "emu" else None
+    if a.context == "emu":
+        from tests.emu import emulib
+        emulib.lib()                                    # build before anything forks
+    K = a.connections
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        src, dst = ChunkStore(Path(tmp) / "src"), Path(tmp) / "dst"
+        q_in, q_out = GatewayQueue(), GatewayQueue()
+        src.add_partition("0", q_in)
+        dst_store = ChunkStore(dst)
+        dq_in, dq_out = GatewayQueue(), GatewayQueue()
+        dst_store.add_partition("0", dq_in)
+        base = synth.mixed_chunks(4, size, config_id=4)
+        digests = {}
+
+        def make(i):
+            cid = uuid.uuid4().hex
+            data = base[i % 4].tobytes()
+            src.get_chunk_file_path(cid).write_bytes(data)
+            digests[cid] = hashlib.md5(data).digest()
+            return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
+
+        warm = [make(i) for i in range(K)]              # one per connection
+        main_reqs = [make(K + i) for i in range(a.chunks)]
+        shares = [[warm[k]] + main_reqs[k::K] for k in range(K)]
+        port_q, done_q = Queue(), Queue()
+        rx = Process(target=receiver_main, args=(dst, port_q, done_q, K))
+        rx.start()
+        port = port_q.get(timeout=120)
+        err_ev, err_q = Event(), Queue()
+        kw = {"context_factory": factory} if factory else {}
+        op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
+                                max_chunk_bytes=size, device_ids=[0], **kw)
+        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=a.workers,
+                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], **kw)
+        total = K + a.chunks
+        ready, ready_cv = {}, threading.Condition()
+        go = threading.Event()
+        stop_drain = threading.Event()
+        status_records = []
+        wire = [0] * K
+
+        def collect():
+            got = 0
+            while got < total and not err_ev.is_set():
+                try:
+                    cr = q_out.q.get(timeout=0.2)
+                except pyqueue.Empty:
+                    continue
+                with ready_cv:
+                    ready[cr.chunk.chunk_id] = cr
+                    ready_cv.notify_all()
+                got += 1
+
+        def drain_status():
+            while not stop_drain.is_set() or not src.chunk_status_queue.empty() or not dst_store.chunk_status_queue.empty():
+                for sq in (src.chunk_status_queue, dst_store.chunk_status_queue):
+                    try:
+                        status_records.append(sq.get(timeout=0.05))
+                    except pyqueue.Empty:
+                        pass
+
+        def send(k):
+            with socket.create_connection(("127.0.0.1", port)) as sock:
+                sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                for idx, cr in enumerate(shares[k]):
+                    if idx == 1:
+                        go.wait(600)                    # the warm-up chunk is through: wait for the clock
+                    with ready_cv:
+                        ready_cv.wait_for(lambda: cr.chunk.chunk_id in ready or err_ev.is_set(), timeout=600)
+                    if err_ev.is_set():
+                        return
+                    dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+                    dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
+                    header, payload = hip_sender.wire_payload(src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
+                    header.to_socket(sock)
+                    sock.sendall(payload)
+                    if idx:
+                        wire[k] += len(payload)
+
+        def wait_decoded(n):
+            got = 0
+            while got < n and not err_ev.is_set():
+                try:
+                    dq_out.q.get(timeout=0.2)
+                    got += 1
+                except pyqueue.Empty:
+                    pass
+            return got
+
+        op.start_workers()
+        dop.start_workers()
+        drainer = threading.Thread(target=drain_status)
+        drainer.start()
+        threads = [threading.Thread(target=collect)] + [threading.Thread(target=send, args=(k,)) for k in range(K)]
+        for t in threads:
+            t.start()
+        t_cold = time.perf_counter()
+        for cr in warm:
+            src.add_chunk_request(cr)
+        assert wait_decoded(K) == K or err_ev.is_set()
+        warm_s = time.perf_counter() - t_cold
+        t0 = time.perf_counter()
+        go.set()
+        for cr in main_reqs:
+            src.add_chunk_request(cr)
+        n_dec = wait_decoded(a.chunks)
+        elapsed = time.perf_counter() - t0
+        for t in threads:
+            t.join(60)
+        n_rx = 0
+        for _ in range(K):
+            n_rx += len(done_q.get(timeout=120))
+        stop_drain.set()
+        op.stop_workers()
+        dop.stop_workers()
+        drainer.join()
+        rx.join(60)
+        assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
+        assert n_dec == a.chunks and n_rx == total
+        for cr in warm + main_reqs:
+            got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
+            assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+        raw = a.chunks * size
+        print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
+                          "max_batch": a.max_batch, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
+                          "status_records": len(status_records), "verified": True}))
+
+
+if __name__ == "__main__":
+    main()

@@ -382,3 +382,19 @@ def test_multi_rank_sharding_gloo_world2():
     assert sorted(s0 + s1) == list(range(13)) and not set(s0) & set(s1) and s0 == list(range(0, 13, 2))
     # every rank reports the same, slowest-rank time; the slow rank slept 2 x 0.1 s inside the timed region
     assert w0 == pytest.approx(w1) and w0 >= max(l0, l1) - 1e-6 and w0 >= 0.19
+
+
+def test_steady_state_e2e_script_with_emulated_device():
+    """scripts/e2e_steady.py end to end on the CPU: both operators run the shipping kernel source under the emulator;
+    sender threads, loopback TCP, deferred receiver, digest registration and the final verification are the real thing."""
+    import json
+    import subprocess
+    import sys
+
+    from tests.emu import emulib
+    emulib.lib()
+    p = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_steady.py"), "--context", "emu", "--chunks", "10", "--chunk-kib", "64",
+                        "--connections", "2", "--max-batch", "4", "--workers", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["verified"] and r["chunks"] == 10 and r["workers"] == 2
