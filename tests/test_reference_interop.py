@@ -72,3 +72,46 @@ def test_reference_daemons_plain_and_with_gpu_compress_operator():
     assert r["verified"] and r["chunks"] == 6 and not r["gpu_op"]
     r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "128", "--connections", "2", "--gpu-op")
     assert r["verified"] and r["gpu_op"] and r["gpu_compress_chunks"] == 6
+
+
+def test_wire_header_differential_against_reference_chunk_py():
+    """Random headers: this repo's WireProtocolHeader / Chunk produce and parse exactly the reference's bytes
+    (skyplane/chunk.py:95-167, loaded by file path: the package __init__ is not importable offline)."""
+    import importlib.util
+    import random
+
+    from skyplane_amd import chunk as mine
+
+    spec = importlib.util.spec_from_file_location("ref_chunk_diff", "/root/reference/skyplane/chunk.py")
+    theirs = importlib.util.module_from_spec(spec)
+    sys.modules["ref_chunk_diff"] = theirs
+    spec.loader.exec_module(theirs)
+    rnd = random.Random(20240921)
+    assert mine.WireProtocolHeader.length_bytes() == theirs.WireProtocolHeader.length_bytes() == 53
+    for _ in range(500):
+        cid = "%032x" % rnd.getrandbits(128)
+        kw = dict(n_chunks_left_on_socket=rnd.choice([0, 1, rnd.getrandbits(20), rnd.getrandbits(63)]),
+                  wire_length=rnd.choice([0, 19, rnd.getrandbits(24), rnd.getrandbits(63)]),
+                  raw_wire_length=rnd.choice([0, 8 << 20, rnd.getrandbits(33), rnd.getrandbits(63)]), is_compressed=rnd.random() < 0.5)
+        a = mine.Chunk(src_key="s", dest_key="d", chunk_id=cid, chunk_length_bytes=kw["raw_wire_length"]).to_wire_header(**kw)
+        b = theirs.Chunk(src_key="s", dest_key="d", chunk_id=cid, chunk_length_bytes=kw["raw_wire_length"]).to_wire_header(**kw)
+        ba, bb = a.to_bytes(), b.to_bytes()
+        assert ba == bb and len(ba) == 53
+        pa, pb = mine.WireProtocolHeader.from_bytes(bb), theirs.WireProtocolHeader.from_bytes(ba)
+        assert (pa.chunk_id, pa.data_len, pa.raw_data_len, pa.is_compressed, pa.n_chunks_left_on_socket) == \
+               (pb.chunk_id, pb.data_len, pb.raw_data_len, pb.is_compressed, pb.n_chunks_left_on_socket) == \
+               (cid, kw["wire_length"], kw["raw_wire_length"], kw["is_compressed"], kw["n_chunks_left_on_socket"])
+    # malformed input is refused the same way
+    good = bytearray(ba)
+    for mutate in (lambda x: x.__setitem__(0, x[0] ^ 1), lambda x: x.__setitem__(11, x[11] ^ 1)):     # magic, version
+        bad = bytearray(good)
+        mutate(bad)
+        for cls in (mine.WireProtocolHeader, theirs.WireProtocolHeader):
+            with pytest.raises(ValueError):
+                cls.from_bytes(bytes(bad))
+    # dict shapes that cross the REST API and the multiprocessing queues
+    c1 = mine.Chunk(src_key="/a", dest_key="b", chunk_id=cid, chunk_length_bytes=5, partition_id="0", file_offset_bytes=7, part_number=2, upload_id="u", multi_part=True)
+    c2 = theirs.Chunk(src_key="/a", dest_key="b", chunk_id=cid, chunk_length_bytes=5, partition_id="0", file_offset_bytes=7, part_number=2, upload_id="u", multi_part=True)
+    assert c1.as_dict() == c2.as_dict()
+    assert mine.ChunkRequest.from_dict(c2.as_dict()).as_dict() == theirs.ChunkRequest.from_dict(c1.as_dict()).as_dict()
+    assert [s.name for s in mine.ChunkState] == [s.name for s in theirs.ChunkState]
