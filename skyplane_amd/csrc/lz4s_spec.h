@@ -1,0 +1,47 @@
+// lz4s_spec.h -- constants of the slice-parallel LZ4 block parse ("lz4s").
+//
+// Shared by the kernel (lz4s_kernel.inc) and by the sequential C restatement of the same parse that the tests use as
+// a bit-exact checker (tests/model/lz4s_model.c).  The parse is deterministic by construction -- every table update is
+// a commutative min, every slice is parsed from read-only tables -- so the GPU, the SIMT emulator and the model must
+// produce identical bytes.  What the reference requires of those bytes is only that lz4.frame.decompress
+// (skyplane/gateway/gateway_receiver.py:195-201) reproduces the chunk; the parse itself is ours.
+#pragma once
+#include <stdint.h>
+
+#define LZ4S_BLOCK 65536u      // one LZ4 frame block (BD = 4), one workgroup
+#define LZ4S_SLICE 64u         // bytes parsed by one lane
+#define LZ4S_LANES 1024u       // lanes per workgroup = slices per block
+#ifndef LZ4S_RLOG
+#define LZ4S_RLOG 14           // log2 of a table region: candidates are kept per 16 KiB region of the block
+#endif
+#ifndef LZ4S_Q
+#define LZ4S_Q 4               // regions per block
+#endif
+#ifndef LZ4S_LOGB
+#define LZ4S_LOGB 12           // log2 buckets; table = buckets x Q entries of 4 bytes = 64 KiB
+#endif
+#ifndef LZ4S_EXT
+#define LZ4S_EXT 256u          // a match may run this far past the end of its slice (overlaps are trimmed afterwards)
+#endif
+#ifndef LZ4S_BACK
+#define LZ4S_BACK 8u           // a match start may move back over at most this many pending literals
+#endif
+#define LZ4S_K1 2654435761u
+#define LZ4S_K3 0x9E3779u      // 24-bit: the fifth byte goes through a full-rate 24-bit multiply-add on the GPU
+#define LZ4S_INF 0xFFFFFFFFu   // empty table entry
+#define LZ4S_TAGMASK 0x7FFFu   // 15-bit tags: an empty entry (tag bits 0xFFFF) can never look like a hit
+
+// hash of the five bytes at a position: g = little-endian dword, b4 = the byte after it
+#define LZ4S_HASH(g, b4) ((uint32_t)(g) * LZ4S_K1 + (uint32_t)(b4) * LZ4S_K3)
+#define LZ4S_BUCKET(x) ((uint32_t)(x) >> (32 - LZ4S_LOGB))
+#define LZ4S_TAG(x) (((uint32_t)(x) >> (32 - LZ4S_LOGB - 15)) & LZ4S_TAGMASK)
+// table entry: tag in the high half so that min() keeps the EARLIEST position among equal tags; the position is
+// relative to its region
+#define LZ4S_ENTRY(tag, relpos) (((uint32_t)(tag) << 16) | (uint32_t)(relpos))
+
+// sequence record produced by the slice parse: offset | literals before the match (from the previous match of the
+// slice or the slice start) << 16 | match length << 22
+#define LZ4S_REC(off, lit, len) ((uint32_t)(off) | ((uint32_t)(lit) << 16) | ((uint32_t)(len) << 22))
+#define LZ4S_REC_OFF(r) ((r) & 0xFFFFu)
+#define LZ4S_REC_LIT(r) (((r) >> 16) & 0x3Fu)
+#define LZ4S_REC_LEN(r) ((r) >> 22)

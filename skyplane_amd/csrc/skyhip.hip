@@ -14,6 +14,7 @@
 #include "wave.h"
 #include "skyhip_kernels.h"
 #include "lz4_kernel.inc"
+#include "lz4s_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
 #include "lz4d_kernel.inc"
@@ -27,6 +28,10 @@
 extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compress(SkyLz4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_compress_body(a, smem);
+}
+extern "C" __global__ void __launch_bounds__(LZ4S_LANES) sky_lz4s_compress(SkyLz4Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4s_compress_body(a, smem);
 }
 extern "C" __global__ void __launch_bounds__(64) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
@@ -145,6 +150,9 @@ struct skyhip_ctx {
     // per-block data for one sub-batch
     DevBuf<uint8_t> d_scratch;
     DevBuf<uint32_t> d_csize, d_blk_word;
+    DevBuf<uint32_t> d_recs;      // slice-parallel compressor: sequence-record scratch, LZ4S_RECS_PER_WG words per workgroup of its grid
+    int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
+    bool lz4_wave_kernel = false; // SKYHIP_LZ4_KERNEL=wave: the round-1 wave-per-block compressor (kept for A/B measurements)
     DevBuf<sky_u64> d_blk_dst;
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
     DevBuf<uint8_t> d_stage_in, d_stage_out;
@@ -257,6 +265,11 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, c->d_blk_word.ensure(nb));
         HIPCHK(c, c->d_blk_dst.ensure(nb));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_compress, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
+        c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
+        HIPCHK(c, c->d_recs.ensure((size_t)c->lz4s_grid * LZ4S_RECS_PER_WG));
+        { const char* e = getenv("SKYHIP_LZ4_KERNEL"); c->lz4_wave_kernel = e && !strcmp(e, "wave"); }
 #ifdef SKY_WITH_CDC
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
 #endif
@@ -265,6 +278,11 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sky_lz4_compress, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES);
             hipFuncAttributes fa;
             (void)hipFuncGetAttributes(&fa, (const void*)sky_lz4_compress);
+            int nbs = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, (const void*)sky_lz4s_compress, LZ4S_LANES, LZ4S_LDS_BYTES);
+            hipFuncAttributes fs;
+            (void)hipFuncGetAttributes(&fs, (const void*)sky_lz4s_compress);
+            fprintf(stderr, "[skyhip] sky_lz4s_compress: %d workgroups/CU (x16 waves), %d VGPRs, %u B dynamic LDS, grid %d\n", nbs, fs.numRegs, (unsigned)LZ4S_LDS_BYTES, c->lz4s_grid);
             fprintf(stderr, "[skyhip] sky_lz4_compress: %d workgroups/CU (x%d waves), %d VGPRs, %zu B static LDS, %d B dynamic LDS, CUs %d, LDS/CU %zu\n", nb,
                     SKY_LZ4_WAVES, fa.numRegs, fa.sharedSizeBytes, SKY_LZ4_LDS_BYTES, prop.multiProcessorCount, prop.maxSharedMemoryPerMultiProcessor);
         }
@@ -287,7 +305,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
-    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release();
+    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release(); c->d_recs.release();
     c->d_stage_in.release(); c->d_stage_out.release();
     for (hipEvent_t e : c->ev_up) (void)hipEventDestroy(e);
     c->ev_up.clear();
@@ -404,6 +422,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing-experiment builds only
 #endif
             la.prof = nullptr;
+            la.recs = c->d_recs.p;
 #if SKY_PROF
             if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8)); }
             la.prof = c->d_prof;
@@ -415,7 +434,8 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             EvPair ep;
             if (nb) {
                 if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
-                hipLaunchKernelGGL(sky_lz4_compress, dim3((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES), dim3(SKY_LZ4_WAVES * 64), SKY_LZ4_LDS_BYTES, c->s_lz4, la);
+                if (c->lz4_wave_kernel) hipLaunchKernelGGL(sky_lz4_compress, dim3((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES), dim3(SKY_LZ4_WAVES * 64), SKY_LZ4_LDS_BYTES, c->s_lz4, la);
+                else hipLaunchKernelGGL(sky_lz4s_compress, dim3(nb < (uint32_t)c->lz4s_grid ? nb : (uint32_t)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_BYTES, c->s_lz4, la);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
                 c->tm.lz4_launches++; c->tm.lz4_in_bytes += sub_bytes;

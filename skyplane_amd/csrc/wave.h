@@ -45,6 +45,8 @@ SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) {
 // arbitrary gather across lanes (ds_bpermute_b32)
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 SKY_DEV void sky_syncthreads() { __syncthreads(); }
+// compiler-only: nothing is scheduled across this point (keeps unrolled load groups from being merged and spilled)
+SKY_DEV void sky_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // compile-time ordering of this wave's LDS/global accesses (lanes of one wave execute DS ops in issue order)
 SKY_DEV void sky_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
@@ -69,6 +71,26 @@ SKY_DEV uint32_t sky_scan_incl_add(uint32_t x) {
         : "+v"(x));
     return x;
 }
+// the same scan with max instead of add (unsigned: the zero that bound_ctrl shifts in is the identity)
+SKY_DEV uint32_t sky_scan_incl_max(uint32_t x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(x));
+    return x;
+}
+SKY_DEV uint32_t sky_wave_max_u32(uint32_t x) { return sky_readlane(sky_scan_incl_max(x), 63); }
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t x) {
     const int lane = sky_lane();
     for (int d = 1; d < 64; d <<= 1) {
@@ -79,6 +101,9 @@ SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t x) {
 }
 
 SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+// LDS atomics (workgroup scope): ds_min_u32 without return, ds_add_rtn_u32
+SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { return atomicMin(p, v); }
 SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 expect, sky_u64 desired) { return atomicCAS(p, expect, desired); }
 SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -86,6 +111,8 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
 // keep a prefetched value alive up to this point (the load warms L2/L1 for a later batch; nothing reads it)
+// returns v, but the compiler may assume nothing about the result (stops CSE / hoisting across this point)
+SKY_DEV uint32_t sky_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 SKY_DEV void sky_keep(uint32_t v) { asm volatile("" ::"v"(v)); }
 #define SKY_RESTRICT __restrict__
 // shader clock (s_memtime) for the SKY_PROF phase-timing build only
@@ -124,3 +151,15 @@ SKY_DEV void sky_st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 struct sky_u128 { uint32_t x, y, z, w; };
 SKY_DEV sky_u128 sky_ld128u(const uint8_t* p) { sky_u128 v; __builtin_memcpy(&v, p, 16); return v; }
 SKY_DEV void sky_st128u(uint8_t* p, const sky_u128& v) { __builtin_memcpy(p, &v, 16); }
+SKY_DEV void sky_st64u(uint8_t* p, sky_u64 v) { __builtin_memcpy(p, &v, 8); }
+// naturally aligned forms (one ds_read_b128 / ds_write_b128 / b64 / b32 on LDS)
+#ifdef SKY_EMU
+SKY_DEV sky_u128 sky_ld128a(const void* p) { sky_u128 v; __builtin_memcpy(&v, p, 16); return v; }
+SKY_DEV void sky_st128a(void* p, const sky_u128& v) { __builtin_memcpy(p, &v, 16); }
+#else
+typedef uint32_t sky_v4u __attribute__((ext_vector_type(4)));     // a 16-byte aligned type: one b128 / dwordx4 access
+SKY_DEV sky_u128 sky_ld128a(const void* p) { const sky_v4u t = *(const sky_v4u*)p; sky_u128 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
+SKY_DEV void sky_st128a(void* p, const sky_u128& v) { sky_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(sky_v4u*)p = t; }
+#endif
+SKY_DEV sky_u64 sky_ld64a(const void* p) { sky_u64 v; __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 8); return v; }
+SKY_DEV uint32_t sky_ld32a(const void* p) { uint32_t v; __builtin_memcpy(&v, __builtin_assume_aligned(p, 4), 4); return v; }

@@ -131,6 +131,10 @@ void emu_launch(int grid, int block, size_t lds_bytes, EmuKernelBody body, void*
                         uint32_t acc = 0;
                         for (int i = 0; i < 64; i++) { if (!wl[i].done) acc += (uint32_t)wl[i].arg0; wl[i].result = acc; }
                     } break;
+                    case EMU_SCANMAX: {
+                        uint32_t acc = 0;
+                        for (int i = 0; i < 64; i++) { if (!wl[i].done && (uint32_t)wl[i].arg0 > acc) acc = (uint32_t)wl[i].arg0; wl[i].result = acc; }
+                    } break;
                     case EMU_WAVESYNC: break;
                     default: fprintf(stderr, "emu: bad op %d\n", op); abort();
                     }

@@ -13,7 +13,7 @@
 #define SKY_WAVE 64
 typedef unsigned long long sky_u64;
 
-enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT, EMU_WAVESYNC };
+enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT, EMU_WAVESYNC, EMU_SCANMAX };
 
 struct EmuLaneState {
     void* sp;            // saved stack pointer of the parked coroutine
@@ -49,7 +49,10 @@ SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)emu_collective
 SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) { return sky_lane() == lane ? val : old; }
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective(EMU_SHFL, v, (sky_u64)(src & 63)); }
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
+SKY_DEV uint32_t sky_scan_incl_max(uint32_t v) { return (uint32_t)emu_collective(EMU_SCANMAX, v, 0); }
+SKY_DEV uint32_t sky_wave_max_u32(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, emu_collective(EMU_SCANMAX, v, 0), 63); }
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
+SKY_DEV void sky_sched_fence() {}
 SKY_DEV void sky_syncthreads() { emu_collective(EMU_BARRIER, 0, 0); }
 // lanes of the emulator run one after the other between collectives; on hardware they run in lock-step, and the
 // kernels put a wave fence wherever a lane reads what another lane of the same wave just wrote: make it a rendezvous
@@ -57,6 +60,8 @@ SKY_DEV void sky_wave_fence() { emu_collective(EMU_WAVESYNC, 0, 0); }
 
 // lanes never run concurrently, so plain read-modify-write is atomic here
 SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { sky_u64 o = *p; if (v < o) *p = v; return o; }
 SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 e, sky_u64 d) { sky_u64 o = *p; if (o == e) *p = d; return o; }
 SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
@@ -64,6 +69,7 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
 SKY_DEV void sky_keep(uint32_t) {}
+SKY_DEV uint32_t sky_opaque(uint32_t v) { return v; }
 #define SKY_RESTRICT
 SKY_DEV sky_u64 sky_clock() { return 0; }
 SKY_DEV uint32_t sky_uniform(uint32_t v) { return v; }

@@ -8,6 +8,7 @@
 #include "wave.h"          // picks up emu.h because SKY_EMU is defined
 #include "skyhip_kernels.h"
 #include "lz4_kernel.inc"
+#include "lz4s_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
 #include "lz4d_kernel.inc"
@@ -16,6 +17,7 @@
 #endif
 
 static void k_lz4(void* a, uint8_t* smem) { sky_lz4_compress_body(*(SkyLz4Args*)a, smem); }
+static void k_lz4s(void* a, uint8_t* smem) { sky_lz4s_compress_body(*(SkyLz4Args*)a, smem); }
 static void k_md5(void* a, uint8_t*) { sky_md5_body(*(SkyMd5Args*)a); }
 static void k_layout(void* a, uint8_t*) { sky_frame_layout_body(*(SkyFrameArgs*)a); }
 static void k_gather(void* a, uint8_t*) { sky_frame_gather_body(*(SkyFrameArgs*)a); }
@@ -46,7 +48,11 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         std::vector<sky_u64> bdst(nb ? nb : 1), flen(n);
         SkyLz4Args la; la.in = in; la.in_off = off.data(); la.in_len = len.data(); la.blk_prefix = prefix.data();
         la.n_chunks = (uint32_t)n; la.n_blocks = nb; la.scratch = scratch.data(); la.csize = csize.data(); la.ablate = 0; la.prof = nullptr;
-        if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
+        const int grid = nb < 3u ? (int)nb : 3;      // a persistent grid smaller than the block count: every workgroup walks several blocks
+        std::vector<uint32_t> recs((size_t)(grid ? grid : 1) * LZ4S_RECS_PER_WG, 0xDEADBEEFu);
+        la.recs = recs.data();
+        if (flags & 0x100u) { if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la); }   // the wave-per-block kernel
+        else if (nb) emu_launch(grid, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
         SkyFrameArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.blk_prefix = prefix.data(); fa.n_chunks = (uint32_t)n;
         fa.n_blocks = nb; fa.scratch = scratch.data(); fa.csize = csize.data(); fa.out = out; fa.out_off = ooff.data(); fa.frame_len = flen.data();
         fa.blk_dst = bdst.data(); fa.blk_word = word.data();
@@ -62,7 +68,20 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
 uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_SLOT bytes */) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
     SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
+    la.recs = nullptr;
     emu_launch(1, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
+    return cs;
+}
+
+// the slice-parallel kernel on one block; dst = SKY_LZ4_SLOT bytes, written only when the block shrinks.  Returns the size.
+uint32_t* emu_dbg_recs = nullptr;
+uint32_t emu_lz4s_block(const uint8_t* src, uint32_t n, uint8_t* dst) {
+    sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
+    std::vector<uint32_t> recs(LZ4S_RECS_PER_WG, 0xDEADBEEFu);
+    SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
+    la.recs = recs.data();
+    emu_launch(1, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
+    if (emu_dbg_recs) memcpy(emu_dbg_recs, recs.data(), LZ4S_RECS_PER_WG * 4);
     return cs;
 }
 
