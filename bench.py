@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- compress+hash stage throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (LZ4 frame + MD5 per 8 MiB chunk) over a device-resident synthetic
-stream: the Silesia-like stand-in of SURVEY.md 8d item 2 (a 256 MiB unit tiled with per-tile rotations).
-Inputs are resident in HBM before the timed region; PCIe is excluded (see DESIGN.md for the host-inclusive rate).
+One "step" = one pass of the hot path (LZ4 frame + MD5 per 8 MiB chunk) over a device-resident synthetic stream.
+  * 1 GPU   : BASELINE configs[1] -- 8192 x 8 MiB = 64 GiB of the Silesia-like stand-in.
+  * N GPUs  : BASELINE configs[3] -- the mixed-compressibility stream (per chunk one of random / text / records+binary /
+              sparse), 16384 chunks = 128 GiB per GPU, processed as two resident halves.  N independent ranks, chunk i of
+              the node's queue on rank i % N, no collective on the data path (weak scaling).
+Inputs are resident in HBM before the timed region; PCIe is excluded (DESIGN.md has the host-inclusive rate).
+Rank 0 prints ONE JSON line.  After the timed region every digest of the step is checked against hashlib and a sample
+of frames against liblz4 (the reference's decoder), on a pool of CPU processes forked before HIP is initialised; the
+same pool times the reference's CPU path (cpu_baseline: one PROCESS per schedulable core).
 
-N GPUs = N independent ranks, chunks sharded round-robin, no collective on the data path (weak scaling: every
-rank processes its own --chunks chunks).  Rank 0 prints ONE JSON line.
+--context emu (tests only): the shipping kernel source under the CPU SIMT emulator, tensors on the host, gloo instead of
+RCCL -- that is how tests/test_host_operator.py runs this file's multi-rank logic with world_size 2 on a box without GPUs.
 """
 import argparse
+import hashlib
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -20,51 +28,131 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402  (must be imported before libskyhip so both share one HIP runtime)
+
+from skyplane_amd import shard, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU side: a pool of worker processes forked BEFORE the HIP runtime exists in this process.  They inherit the synthetic
+# unit (copy-on-write) and do two jobs: the whole-stream verification and the reference CPU baseline.
+# ---------------------------------------------------------------------------------------------------------------------
+_G = {}
 
-def cpu_baseline(host_stream: np.ndarray, chunk_bytes: int, budget_s: float = 12.0):
-    """The reference CPU path restated exactly: per chunk lz4.frame.compress(data) (system liblz4, python-lz4
-    default preferences; gateway_operator.py:359) then hashlib.md5(data).digest() (s3_interface.py:181-192),
-    on a bounded sample of the same stream, one thread per host core."""
-    import hashlib
-    from concurrent.futures import ThreadPoolExecutor
 
+def schedulable_cores():
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:    # cgroup v2 CPU quota, if any
+        q, p = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        pass
+    return n, quota
+
+
+def chunk_view(i, rots, xor_tiles):
+    """Chunk i of the resident stream as (piece, piece) of the host unit: the stream is the unit tiled with a rotation per
+    tile (and, for the dedup stream, XOR-ed with the tile index so that tiles are mutually distinct)."""
+    unit, cb = _G["unit"], _G["cb"]
+    U = unit.size
+    t = (i * cb) // U
+    o = ((i * cb) % U + rots[t]) % U
+    a = unit[o:o + cb]
+    b = unit[:cb - a.size] if a.size < cb else unit[:0]
+    if xor_tiles and (t & 0xFF):
+        a = a ^ np.uint8(t & 0xFF)
+        b = b ^ np.uint8(t & 0xFF)
+    return a, b
+
+
+def _w_md5(args):
+    lo, hi, rots, xor_tiles = args
+    out = []
+    for i in range(lo, hi):
+        a, b = chunk_view(i, rots, xor_tiles)
+        h = hashlib.md5(a)
+        if b.size:
+            h.update(b)
+        out.append(h.digest())
+    return lo, out
+
+
+def _w_baseline(args):
+    """The reference CPU path restated exactly: per chunk lz4.frame.compress(data) (system liblz4 through oracle.ref, python-lz4's
+    default preferences; gateway_operator.py:359) then hashlib.md5(data).digest() (s3_interface.py:181-192)."""
+    wid, nworkers, seconds, rots = args
     from oracle import ref
 
-    cores = os.cpu_count() or 1
-    n_avail = host_stream.size // chunk_bytes
-    bound = ref.lz4f_frame_bound(chunk_bytes)
-
-    def work(tid, deadline, single):
-        out = np.empty(bound, np.uint8)
-        done = 0
-        i = tid
-        while time.perf_counter() < deadline:
-            a = host_stream[(i % n_avail) * chunk_bytes:(i % n_avail + 1) * chunk_bytes]
-            ref.lz4f_compress_into(a, out)
-            hashlib.md5(a).digest()
-            done += 1
-            i += 1 if single else cores
-        return done
-
-    # single core
+    cb = _G["cb"]
+    n_avail = _G["unit"].size // cb
+    out = np.empty(ref.lz4f_frame_bound(cb), np.uint8)
+    buf = np.empty(cb, np.uint8)
+    done, i = 0, wid
     t0 = time.perf_counter()
-    n1 = work(0, t0 + budget_s / 3, True)
-    t1 = time.perf_counter() - t0
-    one = n1 * chunk_bytes / t1 / 2**30
-    # all cores (ctypes and hashlib both release the GIL)
+    while time.perf_counter() - t0 < seconds:
+        a, b = chunk_view(i % n_avail, rots, False)
+        buf[:a.size] = a
+        buf[a.size:] = b
+        ref.lz4f_compress_into(buf, out)
+        hashlib.md5(buf).digest()
+        done += 1
+        i += nworkers
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(pool, cores, quota, rots, budget_s):
+    from oracle import ref
+
+    cb = _G["cb"]
+    (n1, t1), = pool.map(_w_baseline, [(0, 1, budget_s / 3, rots)])
+    one = n1 * cb / t1 / 2**30
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        futs = [ex.submit(work, t, t0 + 2 * budget_s / 3, False) for t in range(cores)]
-        nall = sum(f.result() for f in futs)
-    tall = time.perf_counter() - t0
-    allc = nall * chunk_bytes / tall / 2**30
+    res = pool.map(_w_baseline, [(w, cores, 2 * budget_s / 3, rots) for w in range(cores)], chunksize=1)
+    wall = time.perf_counter() - t0
+    nall = sum(r[0] for r in res)
+    allc = nall * cb / max(r[1] for r in res) / 2**30
     return {"value": round(allc, 3), "unit": "GiB/s", "cores": cores, "kind": "reference",
-            "sample": f"{nall} x 8 MiB chunks of the same stream in {tall:.1f}s, liblz4 {ref.liblz4_version()} LZ4F_compressFrame + hashlib.md5, {cores} threads",
-            "value_1core": round(one, 3)}
+            "sample": f"{nall} x {cb >> 20} MiB chunks of the same stream in {wall:.1f}s: liblz4 {ref.liblz4_version()} LZ4F_compressFrame (python-lz4 default "
+                      f"preferences) + hashlib.md5, one process per schedulable core ({cores}; cgroup cpu quota {quota if quota else 'none'})",
+            "value_1core": round(one, 3), "scaling_efficiency": round(allc / (cores * one), 3) if one > 0 else None}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device side
+# ---------------------------------------------------------------------------------------------------------------------
+class EmuContext:
+    """--context emu: the shipping kernels' source under the CPU emulator (tests/emu).  Same call shape as SkyHipContext."""
+
+    def __init__(self):
+        from tests.emu import emulib
+
+        self.emulib = emulib
+        emulib.lib()
+
+    def process_device(self, t_in, in_off, in_len, t_out, out_off, out_cap, flags):
+        chunks = [t_in[int(o):int(o) + int(l)].tobytes() for o, l in zip(in_off, in_len)]
+        frames, md5s, _ = self.emulib.process(chunks, flags=flags & 3)
+        out_len = np.zeros(len(chunks), np.uint64)
+        for i, f in enumerate(frames):
+            t_out[int(out_off[i]):int(out_off[i]) + len(f)] = np.frombuffer(f, np.uint8)
+            out_len[i] = len(f)
+        return out_len, np.frombuffer(b"".join(md5s), np.uint8).reshape(-1, 16).copy()
+
+    def timing(self):
+        from skyplane_amd._lib import Timing
+
+        return Timing()
+
+    def reset_timing(self):
+        pass
+
+    def dedup_reset(self):
+        pass
+
+    def close(self):
+        pass
 
 
 def main():
@@ -72,171 +160,212 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=0, help="8 MiB chunks per GPU per step (0 = 8192 = 64 GiB if it fits)")
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU per step (0 = the configuration's own: 8192 at 1 GPU, 16384 at N GPUs)")
     ap.add_argument("--unit-mib", type=int, default=256)
-    ap.add_argument("--max-batch", type=int, default=2048, help="chunks per LZ4 sub-batch (scratch = 8.06 MiB each; fewer, larger launches = fewer launch tails)")
+    ap.add_argument("--max-batch", type=int, default=2048, help="chunks per LZ4 launch (block scratch = 8.06 MiB per chunk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stream", choices=["silesia", "mixed"], default="silesia",
-                    help="silesia = configs[1] stand-in (default); mixed = configs[3] stream: every chunk one of {random, text, records+binary, sparse}")
+    ap.add_argument("--stream", choices=["auto", "silesia", "mixed"], default="auto",
+                    help="auto = silesia (configs[1]) on one GPU, mixed (configs[3]) on several")
     ap.add_argument("--cdc", action="store_true", help="configs[2]: add Gear CDC + segment fingerprints + dedup table on a 50 %%-duplicate stream")
+    ap.add_argument("--verify", choices=["full", "sample", "none"], default="full", help="post-run check of digests (all / 64 chunks) and of sampled frames")
+    ap.add_argument("--context", choices=["hip", "emu"], default="hip", help="emu = CPU emulator + gloo (tests of this file's rank logic only)")
+    ap.add_argument("--chunk-bytes", type=int, default=synth.CHUNK_BYTES, help="tests only; the metric is defined on 8 MiB chunks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    emu = args.context == "emu"
+    cb = args.chunk_bytes
+    stream = args.stream if args.stream != "auto" else ("silesia" if world == 1 else "mixed")
+    n_target = args.chunks or (8192 if (stream == "silesia" or args.cdc or world == 1) else 16384)
+
+    # ---- host unit (deterministic), then the CPU pool, then -- and only then -- the HIP runtime ----
+    t0 = time.perf_counter()
+    unit_bytes = min(args.unit_mib << 20, n_target * cb)
+    unit_bytes -= unit_bytes % cb
+    if args.cdc:
+        unit = synth.dedup_stream(unit_bytes, dup_fraction=0.5, config_id=3)
+    elif stream == "mixed":
+        unit = synth.mixed_chunks(unit_bytes // cb, cb, config_id=4).reshape(-1)
+    else:
+        unit = synth.silesia_like(unit_bytes, config_id=2)
+    _G["unit"], _G["cb"] = unit, cb
+    cores, quota = schedulable_cores()
+    want_cpu = rank == 0 and not args.no_cpu_baseline
+    pool_n = cores if want_cpu else max(1, cores // world)
+    pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None
+
+    import torch  # noqa: E402  (imported before libskyhip so both share one HIP runtime; no device touched before the fork above)
+
+    if emu:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from skyplane_amd import hip_ops, synth
+    from skyplane_amd import hip_ops
 
-    cb = synth.CHUNK_BYTES
-    free_b, total_b = torch.cuda.mem_get_info(dev)
-    bound = hip_ops.frame_bound(cb)
+    bound = 15 + cb + 4 * ((cb + 65535) // 65536) + 4 if emu else hip_ops.frame_bound(cb)
     stride = (bound + 255) & ~255
-    scratch = args.max_batch * 128 * 66048
-    n_chunks = args.chunks or 8192
-    while n_chunks > 64 and n_chunks * (cb + stride) + scratch + (6 << 30) > free_b:
-        n_chunks //= 2
-    if world > 1:   # every rank must process the same number of chunks (weak scaling, value = world x chunks x bytes)
+    halves = 2 if (n_target > 8192 and not args.cdc) else 1          # frame slots are reused by the second half
+    n_chunks = n_target
+    if not emu:
+        free_b, _total_b = torch.cuda.mem_get_info(dev)
+        scratch = args.max_batch * 128 * 66048
+        while n_chunks > 64 and n_chunks * cb + (n_chunks // halves) * stride + scratch + (6 << 30) > free_b:
+            n_chunks //= 2
+    if world > 1:   # every rank processes the same number of chunks (weak scaling: value = world x chunks x bytes / time)
         nc = torch.tensor([n_chunks], dtype=torch.int64, device=dev)
         dist.all_reduce(nc, op=dist.ReduceOp.MIN)
         n_chunks = int(nc.item())
-    unit_bytes = min(args.unit_mib << 20, n_chunks * cb)
-    unit_bytes -= unit_bytes % cb
+    n_half = n_chunks // halves
 
-    # ---- synthetic stream: unit generated on the host (deterministic), tiled + rotated on the device ----
-    t0 = time.perf_counter()
-    if args.cdc:
-        unit = synth.dedup_stream(unit_bytes, dup_fraction=0.5, config_id=3)
-    elif args.stream == "mixed":
-        unit = synth.mixed_chunks(unit_bytes // cb, cb, config_id=4).reshape(-1)
-    else:
-        unit = synth.silesia_like(unit_bytes, config_id=2)
+    # ---- the resident stream: the unit tiled and rotated on the device.  This rank holds the chunks rank, rank + world, ... of
+    # the node's queue (chunk_index % n_gpus); with a synthetic queue that is a rank-dependent rotation per tile. ----
     d_unit = torch.from_numpy(unit).to(dev)
     d_in = torch.empty(n_chunks * cb, dtype=torch.uint8, device=dev)
     per = unit_bytes // cb
     n_tiles = (n_chunks + per - 1) // per
     rots = []
     for t in range(n_tiles):
-        # rank-dependent rotation so ranks do not hold byte-identical shards
-        rot = ((t + 131 * rank) * 7919 * 4096 + t * 13) % unit_bytes
+        rot = (((t + 131 * rank) * 7919 * 4096 + t * 13) % unit_bytes) if unit_bytes > cb else 0
+        rot -= rot % cb if stream == "mixed" and not args.cdc else 0     # mixed: the class is a property of the whole chunk -- rotate by whole chunks
         rots.append(rot)
-        lo = t * unit_bytes
-        hi = min(lo + unit_bytes, n_chunks * cb)
+        lo, hi = t * unit_bytes, min((t + 1) * unit_bytes, n_chunks * cb)
         tile = torch.roll(d_unit, -rot)[: hi - lo]
-        if args.cdc and t:
+        if args.cdc and (t & 0xFF):
             tile = tile ^ (t & 0xFF)      # keep the unit's internal duplicate structure, make tiles mutually distinct
         d_in[lo:hi] = tile
-    d_out = torch.empty(n_chunks * stride, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize(dev)
+    del d_unit
+    d_out = torch.empty(n_half * stride, dtype=torch.uint8, device=dev)
+    if not emu:
+        torch.cuda.synchronize(dev)
     gen_s = time.perf_counter() - t0
 
     in_off = np.arange(n_chunks, dtype=np.uint64) * cb
     in_len = np.full(n_chunks, cb, np.uint64)
-    out_off = np.arange(n_chunks, dtype=np.uint64) * stride
-    out_cap = np.full(n_chunks, stride, np.uint64)
+    out_off = np.arange(n_half, dtype=np.uint64) * stride
+    out_cap = np.full(n_half, stride, np.uint64)
 
-    ctx = hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch)
+    if emu:
+        ctx = EmuContext()
+        p_in, p_out = d_in.numpy(), d_out.numpy()
+    else:
+        ctx = hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch)
+        p_in, p_out = d_in.data_ptr(), d_out.data_ptr()
     flags = hip_ops.F_LZ4 | hip_ops.F_MD5 | ((hip_ops.F_CDC | hip_ops.F_DEDUP) if args.cdc else 0)
+    last = {}
 
     def step():
         if args.cdc:
             ctx.dedup_reset()      # every step sees the stream for the first time
-        return ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, flags)
+        lens, digs = [], []
+        for h in range(halves):
+            sl = slice(h * n_half, (h + 1) * n_half)
+            ol, md = ctx.process_device(p_in, in_off[sl], in_len[sl], p_out, out_off, out_cap, flags)
+            lens.append(ol); digs.append(md)
+        last["out_len"], last["md5"] = np.concatenate(lens), np.concatenate(digs)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def sync():
+        if not emu:
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
     ctx.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_len, md5 = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    _local, elapsed = shard.timed_region(step, args.steps, dist=dist, sync=sync)      # barrier + synchronize on both sides, MAX over ranks
     tm = ctx.timing()
+    out_len, md5 = last["out_len"], last["md5"]
+
+    # ---- verification, outside the timed region: every digest of the last step, a sample of the frames of its last half ----
+    verified = {"digests": 0, "frames": 0}
+    if args.verify != "none":
+        idx = list(range(n_chunks)) if args.verify == "full" else sorted(set(np.linspace(0, n_chunks - 1, 64).astype(int).tolist()))
+        spans = [(idx[k], idx[k] + 1) for k in range(len(idx))] if args.verify != "full" else [(lo, min(lo + 16, n_chunks)) for lo in range(0, n_chunks, 16)]
+        for lo, digs in pool.imap_unordered(_w_md5, [(lo, hi, rots, args.cdc) for lo, hi in spans], chunksize=1):
+            for k, d in enumerate(digs):
+                assert md5[lo + k].tobytes() == d, f"rank {rank}: md5 of chunk {lo + k} differs from hashlib"
+        verified["digests"] = len(idx)
+        from oracle import ref
+
+        for j in sorted(set(np.linspace(0, n_half - 1, 24).astype(int).tolist())):
+            i = (halves - 1) * n_half + j
+            a, b = chunk_view(i, rots, args.cdc)
+            f = d_out[int(out_off[j]):int(out_off[j]) + int(out_len[i])].cpu().numpy()
+            assert ref.lz4f_decompress(f, cb) == a.tobytes() + b.tobytes(), f"rank {rank}: frame of chunk {i} does not decode to the chunk (liblz4)"
+            verified["frames"] += 1
+    dd = hashlib.md5(md5.tobytes()).hexdigest()      # digest of digests of this rank's stream
+    ok = 1
+    if world > 1:
+        okt = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # a failed assert on any rank kills the job before this line
+        ok = int(okt.item())
 
     if rank == 0:
         total_bytes = world * n_chunks * cb * args.steps
         value = total_bytes / elapsed / 2**30
         comp_bytes = int(out_len.sum())
-        # dominant kernel: sky_lz4_compress.  algorithmic bytes per launch = raw bytes read + frame bytes produced
-        # (N + C per chunk; the 16-byte digest and cut offsets are negligible), divided by the HIP-event
-        # duration of that kernel on the library's LZ4 stream.
+        cfg_id = "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table)" if args.cdc else ("configs[1]" if stream == "silesia" else ("configs[3]" if world > 1 else "configs[3] stream on one GPU"))
+        sdesc = ("synthetic stream with ~50 % of its 8-64 KiB spans copied from earlier spans at unaligned offsets" if args.cdc else
+                 "Silesia-like synthetic stream (no Silesia corpus offline)" if stream == "silesia" else
+                 "mixed-compressibility stream (per chunk one of random / text / records+binary / sparse)")
+        # dominant kernel: the LZ4 compressor.  algorithmic bytes per launch = raw bytes read + frame bytes produced (N + C per
+        # chunk; the 16-byte digest and cut offsets are negligible), divided by the HIP-event duration of that kernel on the library's stream.
         lz4_s = tm.lz4_ms / 1e3
         achieved = (tm.lz4_in_bytes + tm.lz4_out_bytes) / lz4_s / 1e9 if lz4_s > 0 else 0.0
+        kname = "sky_lz4_compress" if os.environ.get("SKYHIP_LZ4_KERNEL") == "wave" else "sky_lz4s_compress"
         res = {
             "metric": "GiB/s through compress+hash stage (input bytes)", "value": round(value, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1 MI355X, 8 MiB chunks, LZ4 frame + MD5 HIP kernels, Silesia-like synthetic stream "
-                                   f"({n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks, {unit_bytes >> 20} MiB unit tiled+rotated; no Silesia corpus offline)",
+            "config": {"workload": f"{cfg_id}: {world} MI355X, {cb >> 20} MiB chunks, LZ4 frame + MD5 HIP kernels, {sdesc}; "
+                                   f"{n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks per step in {halves} resident half(s), {unit_bytes >> 20} MiB unit tiled + rotated",
                        "chunk_bytes": cb, "chunks_per_gpu": n_chunks, "lz4_ratio": round(n_chunks * cb / comp_bytes, 4),
-                       "sharding": "round-robin, no collective" if world > 1 else "single GPU", "max_batch": args.max_batch},
-            "roofline": {"bound": "hbm", "kernel": "sky_lz4_compress", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "sharding": "chunk i of the node's queue on rank i % N, no collective on the data path" if world > 1 else "single GPU", "max_batch": args.max_batch},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "avg_launch_ms": round(tm.lz4_ms / max(tm.lz4_launches, 1), 4), "launches": int(tm.lz4_launches),
                          "algorithmic_bytes_per_launch": int((tm.lz4_in_bytes + tm.lz4_out_bytes) / max(tm.lz4_launches, 1))},
             "kernels_ms_per_step": {"lz4": round(tm.lz4_ms / args.steps, 3), "layout": round(tm.layout_ms / args.steps, 3),
                                     "gather": round(tm.gather_ms / args.steps, 3), "md5": round(tm.md5_ms / args.steps, 3)},
+            "verified": {"digests_vs_hashlib": verified["digests"], "frames_vs_liblz4": verified["frames"], "digest_of_digests": dd, "all_ranks_ok": bool(ok)},
             "setup_s": round(gen_s, 1),
         }
-        # HBM-side traffic of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE cannot be collected inside this run
-        # (separate rocprofv3 --pmc passes, scripts/pmc.sh); the committed per-input-byte factors are applied here.
+        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (scripts/pmc.sh); a committed measurement is
+        # quoted only for the kernel and stream it was taken on
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
-            t = json.loads(tf.read_text())
-            per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
-            res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
-            res["roofline"]["traffic_source"] = t["source"]
-        if args.stream == "mixed" and not args.cdc:
-            res["config"]["workload"] = (res["config"]["workload"].replace("configs[1]", "configs[3] stream on one GPU")
-                                         .replace("Silesia-like synthetic stream", "mixed-compressibility stream (per chunk one of random / text / records+binary / sparse)"))
+            t = json.loads(tf.read_text()).get(f"{kname}:{'cdc' if args.cdc else stream}")
+            if t:
+                per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
+                res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
+                res["roofline"]["traffic_source"] = t["source"]
         if args.cdc:
-            res["config"]["workload"] = (res["config"]["workload"].replace("configs[1]", "configs[2] (+ Gear CDC, segment MD5 fingerprints, dedup table)")
-                                         .replace("Silesia-like synthetic stream", "synthetic stream with ~50 % of its 8-64 KiB spans copied from earlier spans at unaligned offsets")
-                                         .replace("tiled+rotated; no Silesia corpus offline", "tiled, rotated and XOR-ed per tile so that tiles are mutually distinct"))
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
             prefix, cuts, fps, first, base = ctx.cdc_results(n_chunks, in_len)
-            import numpy as _np
-            seg_end = cuts.astype(_np.int64)
-            seg_start = _np.concatenate([[0], seg_end[:-1]])
-            seg_start[prefix[:-1][prefix[:-1] < prefix[1:]].astype(_np.int64)] = 0      # first segment of every chunk starts at 0
+            seg_end = cuts.astype(np.int64)
+            seg_start = np.concatenate([[0], seg_end[:-1]])
+            seg_start[prefix[:-1][prefix[:-1] < prefix[1:]].astype(np.int64)] = 0      # first segment of every chunk starts at 0
             seg_len = seg_end - seg_start
-            dup = first != _np.arange(base, base + len(first), dtype=_np.uint64)
+            dup = first != np.arange(base, base + len(first), dtype=np.uint64)
             res["config"]["segments"] = int(len(first)); res["config"]["avg_segment_bytes"] = round(float(seg_len.mean()), 1)
             res["config"]["duplicate_bytes_fraction"] = round(float(seg_len[dup].sum() / seg_len.sum()), 4)
-        # spot check (outside the timed region): first and last chunk against the oracle
-        import hashlib
-
-        from oracle import ref
-
-        for i in (0, n_chunks - 1):
-            t = i * cb // unit_bytes
-            raw = np.roll(unit, -rots[t])[(i * cb) % unit_bytes:(i * cb) % unit_bytes + cb]
-            if args.cdc and t:
-                raw = raw ^ np.uint8(t & 0xFF)
-            assert md5[i].tobytes() == hashlib.md5(raw).digest(), f"bench spot check: md5 of chunk {i}"
-            f = d_out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].cpu().numpy()
-            assert ref.lz4f_decompress(f, cb) == raw.tobytes(), f"bench spot check: frame of chunk {i}"
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(unit, cb)
+        if want_cpu:
+            res["cpu_baseline"] = cpu_baseline(pool, cores, quota, rots, 12.0 if world == 1 else 6.0)
         print(json.dumps(res), flush=True)
+    if pool is not None:
+        pool.close(); pool.join()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -50,7 +50,8 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         la.n_chunks = (uint32_t)n; la.n_blocks = nb; la.scratch = scratch.data(); la.csize = csize.data(); la.ablate = 0; la.prof = nullptr;
         const int grid = nb < 3u ? (int)nb : 3;      // a persistent grid smaller than the block count: every workgroup walks several blocks
         std::vector<uint32_t> recs((size_t)(grid ? grid : 1) * LZ4S_RECS_PER_WG, 0xDEADBEEFu);
-        la.recs = recs.data();
+        uint32_t qhead = 0;
+        la.recs = recs.data(); la.queue = &qhead;
         if (flags & 0x100u) { if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la); }   // the wave-per-block kernel
         else if (nb) emu_launch(grid, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
         SkyFrameArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.blk_prefix = prefix.data(); fa.n_chunks = (uint32_t)n;
@@ -68,7 +69,7 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
 uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_SLOT bytes */) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
     SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
-    la.recs = nullptr;
+    la.recs = nullptr; la.queue = nullptr;
     emu_launch(1, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
     return cs;
 }
@@ -79,7 +80,8 @@ uint32_t emu_lz4s_block(const uint8_t* src, uint32_t n, uint8_t* dst) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
     std::vector<uint32_t> recs(LZ4S_RECS_PER_WG, 0xDEADBEEFu);
     SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
-    la.recs = recs.data();
+    uint32_t qhead = 0;
+    la.recs = recs.data(); la.queue = &qhead;
     emu_launch(1, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
     if (emu_dbg_recs) memcpy(emu_dbg_recs, recs.data(), LZ4S_RECS_PER_WG * 4);
     return cs;

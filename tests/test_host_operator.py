@@ -384,6 +384,33 @@ def test_multi_rank_sharding_gloo_world2():
     assert w0 == pytest.approx(w1) and w0 >= max(l0, l1) - 1e-6 and w0 >= 0.19
 
 
+def test_bench_py_rank_logic_world2_gloo():
+    """bench.py's OWN multi-rank path (the code the driver launches with --gpus N): two ranks under torch.distributed.run, gloo,
+    the shipping kernels under the emulator as the device.  Checks the configs[3] workload label, the rank-dependent streams, the
+    all-ranks verification and the max-over-ranks timing -- on a box without a GPU."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    from tests.emu import emulib
+    emulib.lib()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "bench.py"), "--gpus", "2", "--context", "emu", "--chunk-bytes", "131072", "--chunks", "8", "--unit-mib", "1", "--steps", "2",
+           "--warmup", "1", "--max-batch", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 2 and r["config"]["workload"].startswith("configs[3]: 2 MI355X")
+    assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 8 and r["verified"]["frames_vs_liblz4"] == 8
+    assert r["value"] > 0 and abs(r["value"] - 2 * 8 * 131072 * 2 / (r["ms_per_step"] * 2 / 1e3) / 2**30) < 0.01 * r["value"] + 1e-3
+
+
 def test_steady_state_e2e_script_with_emulated_device():
     """scripts/e2e_steady.py end to end on the CPU: both operators run the shipping kernel source under the emulator;
     sender threads, loopback TCP, deferred receiver, digest registration and the final verification are the real thing."""
