@@ -115,7 +115,7 @@ def cpu_baseline(pool, cores, quota, rots, budget_s):
     allc = nall * cb / max(r[1] for r in res) / 2**30
     return {"value": round(allc, 3), "unit": "GiB/s", "cores": cores, "kind": "reference",
             "sample": f"{nall} x {cb >> 20} MiB chunks of the same stream in {wall:.1f}s: liblz4 {ref.liblz4_version()} LZ4F_compressFrame (python-lz4 default "
-                      f"preferences) + hashlib.md5, one process per schedulable core ({cores}; cgroup cpu quota {quota if quota else 'none'})",
+                      f"preferences) + hashlib.md5, one process per schedulable core ({cores} = min(affinity mask {len(os.sched_getaffinity(0))}, cgroup cpu quota {quota if quota else 'none'}))",
             "value_1core": round(one, 3), "scaling_efficiency": round(allc / (cores * one), 3) if one > 0 else None}
 
 
@@ -193,6 +193,8 @@ def main():
         unit = synth.silesia_like(unit_bytes, config_id=2)
     _G["unit"], _G["cb"] = unit, cb
     cores, quota = schedulable_cores()
+    if quota:       # a container with a CPU quota cannot run more than that many processes at once, whatever its affinity mask says
+        cores = max(1, min(cores, int(quota + 0.5)))
     want_cpu = rank == 0 and not args.no_cpu_baseline
     pool_n = cores if want_cpu else max(1, cores // world)
     pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None

@@ -91,7 +91,7 @@ def _emu_context_factory(device_id, max_chunk_bytes, max_batch):
     return EmuContext()
 
 
-def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, log):
+def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, log, context="emu"):
     """Child process: one reference GatewayDaemon."""
     fd = os.open(log, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     os.dup2(fd, 1)
@@ -127,7 +127,7 @@ def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, 
         d_mod = types.ModuleType("skyplane.gateway.gateway_daemon")
         d_mod.__file__ = str(d_path)
         d_mod.GatewayHipCompress = GatewayHipCompress
-        d_mod.GPU_CONTEXT_FACTORY = _emu_context_factory
+        d_mod.GPU_CONTEXT_FACTORY = _emu_context_factory if context == "emu" else None      # None: SkyHipContext on a real GPU, created after the fork
         exec(compile(_apply(d_path.read_text(), DAEMON_EDITS, "daemon patch").replace('if __name__ == "__main__":', "if False:"), str(d_path), "exec"), d_mod.__dict__)
         GatewayDaemon = d_mod.GatewayDaemon
     else:
@@ -221,6 +221,11 @@ def main():
     ap.add_argument("--chunk-kib", type=int, default=8192)
     ap.add_argument("--connections", type=int, default=4)
     ap.add_argument("--gpu-op", action="store_true")
+    ap.add_argument("--context", choices=["emu", "hip"], default="emu", help="device behind gpu_compress: the CPU emulator (build container) or a real MI355X")
+    ap.add_argument("--workers", type=int, default=1, help="gpu_compress worker processes")
+    ap.add_argument("--max-batch", type=int, default=8)
+    ap.add_argument("--stream", choices=["silesia", "random"], default="silesia", help="random = BASELINE configs[0]'s PRNG bytes")
+    ap.add_argument("--timeout", type=int, default=600)
     ap.add_argument("--out", default="")
     ap.add_argument("--keep-logs", action="store_true")
     a = ap.parse_args()
@@ -241,7 +246,7 @@ def main():
     src_dir, dst_dir = work / "src_bucket", work / "dst_bucket"
     src_dir.mkdir()
     dst_dir.mkdir()
-    unit = synth.silesia_like(min(a.chunks, 16) * size, config_id=2)
+    unit = synth.silesia_like(min(a.chunks, 16) * size, config_id=2) if a.stream == "silesia" else synth.gen_random(synth.rng_for(1), min(a.chunks, 16) * size)
     chunks, datas = [], {}
     for i in range(a.chunks):
         cid = uuid.uuid4().hex
@@ -255,7 +260,7 @@ def main():
     send = {"op_type": "send", "handle": "send", "target_gateway_id": "dst", "region": "local:dst", "num_connections": a.connections, "compress": True,
             "encrypt": False, "private_ip": False, "children": []}
     if a.gpu_op:
-        mid = {"op_type": "gpu_compress", "handle": "gpu", "num_workers": 1, "max_batch": 8, "max_chunk_mb": 64, "compute_md5": True, "cdc": False,
+        mid = {"op_type": "gpu_compress", "handle": "gpu", "num_workers": a.workers, "max_batch": a.max_batch, "max_chunk_mb": 64, "compute_md5": True, "cdc": False,
                "dedup": False, "children": [send]}
     else:
         mid = send
@@ -270,14 +275,15 @@ def main():
                    check=True, capture_output=True)
     stop = threading.Event()
     threading.Thread(target=tls_front, args=(DST_TLS, DST_API, str(cert), str(key), stop), daemon=True).start()
-    if a.gpu_op:
+    if a.gpu_op and a.context == "emu":
         from tests.emu import emulib
         emulib.lib()                            # build once, before the daemons fork their workers
     procs = [Process(target=daemon_main, args=("dst", "local:dst", str(work / "dst_chunks"), dst_program, info, DST_API, str(work), False, str(work / "dst.log"))),
-             Process(target=daemon_main, args=("src", "local:src", str(work / "src_chunks"), src_program, info, SRC_API, str(work), a.gpu_op, str(work / "src.log")))]
+             Process(target=daemon_main, args=("src", "local:src", str(work / "src_chunks"), src_program, info, SRC_API, str(work), a.gpu_op, str(work / "src.log"), a.context))]
     res = {"what": "two reference GatewayDaemons on localhost: read_object_store(local) -> " + ("gpu_compress -> " if a.gpu_op else "") +
                    "send(compress) -> receive -> write_object_store(local)", "chunks": a.chunks, "chunk_bytes": size, "connections": a.connections,
-           "host_cores": os.cpu_count(), "gpu_op": bool(a.gpu_op)}
+           "host_cores": os.cpu_count(), "schedulable_cores": len(os.sched_getaffinity(0)), "gpu_op": bool(a.gpu_op), "context": a.context if a.gpu_op else None,
+           "stream": a.stream, "gpu_workers": a.workers if a.gpu_op else None}
     ok = False
     try:
         for p in procs:
@@ -287,7 +293,7 @@ def main():
         t0 = time.time()
         r = http_json("POST", f"http://127.0.0.1:{SRC_API}/api/v1/chunk_requests", chunks)
         assert r["n_added"] == len(chunks), r
-        deadline = time.time() + 600
+        deadline = time.time() + a.timeout
         done = 0
         while time.time() < deadline:
             for port in (SRC_API, DST_API):

@@ -7,7 +7,7 @@ gateway modules on the hot path do not need them, so a scratch directory is put 
                             (oracle/ref.py; python-lz4 4.3.2 itself is not installed)
   nacl/secret.py, OpenSSL/__init__.py -- empty stand-ins (TLS and e2ee stay off)
 (SURVEY.md 8c describes the same shim.)  Nothing from /root/reference is copied; the directory lives in a tmp dir.
-The GPU box has no /root/reference: callers must check `available()` and skip.
+The GPU box has no /root/reference: there the tree staged by oracle/stage_reference.py is used; callers still check `available()`.
 """
 from __future__ import annotations
 
@@ -15,8 +15,10 @@ import os
 import sys
 from pathlib import Path
 
-REFERENCE = Path("/root/reference")
 _REPO = Path(__file__).resolve().parents[1]
+# the read-only reference tree (build container) or, on the GPU box, the copy oracle/stage_reference.py staged under oracle/_ref/
+# (git-ignored, travels with gpurun)
+REFERENCE = Path("/root/reference") if Path("/root/reference/skyplane/chunk.py").is_file() else _REPO / "oracle" / "_ref"
 
 
 def available() -> bool:

@@ -16,10 +16,14 @@ stride = (hip_ops.frame_bound(cb) + 255) & ~255
 d_out = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
 in_off = np.arange(n, dtype=np.uint64) * cb; in_len = np.full(n, cb, np.uint64)
 out_off = np.arange(n, dtype=np.uint64) * stride; out_cap = np.full(n, stride, np.uint64)
+torch.cuda.synchronize()      # the library runs on its own streams: the stream must be complete before it is handed over
 ctx = hip_ops.SkyHipContext(0, cb, n)
 names = ["load + table clear", "pre-pass", "barrier (pre-pass)", "probe-all", "parse", "scan 1 (waits for the slowest parse)", "records + pass A", "scans 2-4",
          "emit", "barrier + bulk copies", "flush + barrier", "block total", "blocks x waves"]
-for label, flags in (("lz4", hip_ops.F_LZ4), ("md5", hip_ops.F_MD5), ("lz4+md5", hip_ops.F_LZ4 | hip_ops.F_MD5)):
+runs = (("lz4", hip_ops.F_LZ4), ("md5", hip_ops.F_MD5), ("lz4+md5", hip_ops.F_LZ4 | hip_ops.F_MD5))
+if os.environ.get("ONLY"):
+    runs = tuple(r for r in runs if r[0] == os.environ["ONLY"])
+for label, flags in runs:
     ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, flags)
     pr = (ctypes.c_uint64 * 16)(); ctx._lib.skyhip_debug_prof(ctx._h, pr)      # discard the warm-up
     ctx.reset_timing()

@@ -33,7 +33,7 @@ extern "C" __global__ void __launch_bounds__(LZ4S_LANES) sky_lz4s_compress(SkyLz
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4s_compress_body(a, smem);
 }
-extern "C" __global__ void __launch_bounds__(512) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }
@@ -151,9 +151,9 @@ struct skyhip_ctx {
     DevBuf<uint8_t> d_scratch;
     DevBuf<uint32_t> d_csize, d_blk_word;
     DevBuf<uint32_t> d_queue;     // slice-parallel compressor: block queue head
-    DevBuf<uint32_t> d_recs;      // slice-parallel compressor: sequence-record scratch, LZ4S_RECS_PER_WG words per workgroup of its grid
-    int md5_wg = 512;             // lanes per MD5 workgroup: the digests' few, long-running waves are packed onto few CUs so that the
-                                  // compressor's workgroups (a whole CU's registers each) find the other CUs free
+    int md5_wg = 64;              // lanes per MD5 workgroup.  One wave per CU is as fast as MD5 gets: every lane streams its own chunk (64 cache lines per
+                                  // load instruction), and a CU's memory path serves one such wave at full chain speed -- 2048 chunks take 98 ms as 64-lane
+                                  // workgroups, 187 ms as 256-lane, 374 ms as 512-lane ones (profiles/r2_md5_workgroup.txt).  SKYHIP_MD5_WG overrides.
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
     bool lz4_wave_kernel = false; // SKYHIP_LZ4_KERNEL=wave: the round-1 wave-per-block compressor (kept for A/B measurements)
     DevBuf<sky_u64> d_blk_dst;
@@ -271,9 +271,8 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
-        HIPCHK(c, c->d_recs.ensure((size_t)c->lz4s_grid * LZ4S_RECS_PER_WG));
         HIPCHK(c, c->d_queue.ensure(16));
-        { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 1024 && v % 64 == 0) c->md5_wg = v; }
+        { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) c->md5_wg = v; }
         { const char* e = getenv("SKYHIP_LZ4_KERNEL"); c->lz4_wave_kernel = e && !strcmp(e, "wave"); }
 #ifdef SKY_WITH_CDC
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
@@ -310,7 +309,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
-    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release(); c->d_recs.release(); c->d_queue.release();
+    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release(); c->d_queue.release();
     c->d_stage_in.release(); c->d_stage_out.release();
     for (hipEvent_t e : c->ev_up) (void)hipEventDestroy(e);
     c->ev_up.clear();
@@ -427,7 +426,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing-experiment builds only
 #endif
             la.prof = nullptr;
-            la.recs = c->d_recs.p; la.queue = c->d_queue.p;
+            la.queue = c->d_queue.p;
 #if SKY_PROF
             if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8)); }
             la.prof = c->d_prof;

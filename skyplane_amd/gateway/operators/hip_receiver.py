@@ -18,7 +18,13 @@ from skyplane_amd.gateway.chunk_store import ChunkStore
 MB = 1024 * 1024
 
 
-def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Optional[Callable[[bytes, int], bytes]], recv_block_size: int = 4 * MB) -> List[str]:
+def frame_bound(raw_len: int) -> int:
+    """Largest LZ4 frame a conforming sender can make of raw_len bytes (15-byte header, 4 bytes per 64 KiB block, EndMark)."""
+    return 15 + raw_len + 4 * ((raw_len + 65535) // 65536) + 4
+
+
+def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Optional[Callable[[bytes, int], bytes]], recv_block_size: int = 4 * MB,
+                max_chunk_bytes: int = 1024 * MB) -> List[str]:
     """`decompress(frame, raw_len)` stands where lz4.frame.decompress stands in the reference, e.g.
     ``lambda f, n: ctx.decompress_batch([f], [n])[0]`` with a SkyHipContext.
     ``decompress=None`` defers the decode to the batching ``gpu_decompress`` operator (GatewayHipDecompress): a
@@ -27,6 +33,27 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
     received: List[str] = []
     while True:
         header = WireProtocolHeader.from_socket(conn)
+        # the header is untrusted input: bound both lengths before anything is allocated (the reference trusts them, :177-188)
+        if header.raw_data_len > max_chunk_bytes or header.data_len > frame_bound(max_chunk_bytes):
+            raise ValueError(f"[Gateway] chunk {header.chunk_id}: header announces {header.data_len} wire / {header.raw_data_len} raw bytes, limit {max_chunk_bytes}")
+        if header.is_compressed and decompress is None:
+            # deferred decode: stream the payload to its sidecar in recv_block_size pieces, never holding it whole
+            final = sidecar.compressed_path(chunk_store, header.chunk_id)
+            tmp = final.with_suffix(".rxtmp")
+            buf = bytearray(min(header.data_len, recv_block_size) or 1)
+            got = 0
+            with open(tmp, "wb") as f:
+                while got < header.data_len:
+                    n = conn.recv_into(buf, min(header.data_len - got, len(buf)))
+                    if n == 0:
+                        raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
+                    f.write(memoryview(buf)[:n])
+                    got += n
+            os.replace(tmp, final)
+            received.append(header.chunk_id)
+            if header.n_chunks_left_on_socket == 0:
+                return received
+            continue
         payload = bytearray(header.data_len)
         view, got = memoryview(payload), 0
         while got < header.data_len:
@@ -34,15 +61,6 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
             if n == 0:
                 raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
             got += n
-        if header.is_compressed and decompress is None:
-            final = sidecar.compressed_path(chunk_store, header.chunk_id)
-            tmp = final.with_suffix(".rxtmp")
-            tmp.write_bytes(payload)
-            os.replace(tmp, final)
-            received.append(header.chunk_id)
-            if header.n_chunks_left_on_socket == 0:
-                return received
-            continue
         data = decompress(bytes(payload), header.raw_data_len) if header.is_compressed else bytes(payload)
         if len(data) != header.raw_data_len:
             raise ValueError(f"[Gateway] chunk {header.chunk_id}: {len(data)} bytes after decoding, header says {header.raw_data_len}")

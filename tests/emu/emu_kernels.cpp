@@ -49,9 +49,8 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         SkyLz4Args la; la.in = in; la.in_off = off.data(); la.in_len = len.data(); la.blk_prefix = prefix.data();
         la.n_chunks = (uint32_t)n; la.n_blocks = nb; la.scratch = scratch.data(); la.csize = csize.data(); la.ablate = 0; la.prof = nullptr;
         const int grid = nb < 3u ? (int)nb : 3;      // a persistent grid smaller than the block count: every workgroup walks several blocks
-        std::vector<uint32_t> recs((size_t)(grid ? grid : 1) * LZ4S_RECS_PER_WG, 0xDEADBEEFu);
         uint32_t qhead = 0;
-        la.recs = recs.data(); la.queue = &qhead;
+        la.queue = &qhead;
         if (flags & 0x100u) { if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la); }   // the wave-per-block kernel
         else if (nb) emu_launch(grid, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
         SkyFrameArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.blk_prefix = prefix.data(); fa.n_chunks = (uint32_t)n;
@@ -69,21 +68,18 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
 uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_SLOT bytes */) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
     SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
-    la.recs = nullptr; la.queue = nullptr;
+    la.queue = nullptr;
     emu_launch(1, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
     return cs;
 }
 
 // the slice-parallel kernel on one block; dst = SKY_LZ4_SLOT bytes, written only when the block shrinks.  Returns the size.
-uint32_t* emu_dbg_recs = nullptr;
 uint32_t emu_lz4s_block(const uint8_t* src, uint32_t n, uint8_t* dst) {
     sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
-    std::vector<uint32_t> recs(LZ4S_RECS_PER_WG, 0xDEADBEEFu);
     SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
     uint32_t qhead = 0;
-    la.recs = recs.data(); la.queue = &qhead;
+    la.queue = &qhead;
     emu_launch(1, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
-    if (emu_dbg_recs) memcpy(emu_dbg_recs, recs.data(), LZ4S_RECS_PER_WG * 4);
     return cs;
 }
 
@@ -162,7 +158,7 @@ long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, 
         da.first_seen = fs.data(); da.err = err.data();
         emu_launch((slots + 255) / 256, 256, 0, k_dins, &da);
         emu_launch((slots + 255) / 256, 256, 0, k_dres, &da);
-        if (err[0]) return -7;
+        // err[0] = segments that found no slot within the probe bound: reported as "not seen before", not an error
     }
     for (int i = 0; i <= n; i++) seg_prefix_out[i] = seg_prefix[i];
     for (uint32_t i = 0; i < total; i++) { seg_end_out[i] = seg_end[i]; if (dedup) first_seen_out[i] = fs[i]; }

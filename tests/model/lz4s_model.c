@@ -28,7 +28,6 @@ typedef struct { uint32_t n_rec, n_kept, n_trimmed, n_dropped, n_probe_fail; } l
 
 // Compress one block of n <= 65536 bytes.  Returns the compressed size; writes the block when dst != NULL
 // (dst must hold n + n/255 + 16 bytes).  recs_out (optional, 16 * LZ4S_LANES words) receives the raw per-slice records.
-uint32_t* lz4s_dbg_recs = 0; uint32_t* lz4s_dbg_nrec = 0;
 uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats* st) {
     const uint32_t NB = 1u << LZ4S_LOGB;
     uint32_t* T = (uint32_t*)malloc((size_t)NB * LZ4S_Q * 4);
@@ -51,24 +50,27 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
         for (uint32_t j = 0; j < nsl; j++) {
             const uint32_t s0 = j * LZ4S_SLICE, s1 = s0 + LZ4S_SLICE < n ? s0 + LZ4S_SLICE : n;
             const uint32_t lim = s1 + LZ4S_EXT < matchlimit ? s1 + LZ4S_EXT : matchlimit;
-            uint32_t pos = s0, lanchor = s0;
-            for (uint32_t p = s0; p < s1 && p <= mflimit; p++) {
+            uint32_t pos = s0, lanchor = s0, visits = 0;
+            for (uint32_t p = s0; p < s1 && p <= mflimit && visits < 16u; p++) {
                 if (p < pos) continue;
                 const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
                 const uint32_t q = p >> LZ4S_RLOG, tb = LZ4S_TAG(x) << 16, rel = p & ((1u << LZ4S_RLOG) - 1u);
                 const uint32_t* e = &T[LZ4S_BUCKET(x) * LZ4S_Q];
                 uint32_t best = 0, bc = 0;
+                int cand = 0;
                 const uint32_t cap8 = lim - p < 8u ? lim - p : 8u;
                 // short-period candidate (runs, "abab", 32-bit patterns): the 4 bytes before p repeat at p.  Overlapping
                 // copies run as long as the period holds, which no table entry (the EARLIEST occurrence) can offer.
-                if (p >= 4u && rd32(s + p - 4u) == rd32(s + p)) { best = common(s + p, s + p - 4u, cap8); bc = p - 4u; }
+                if (p >= 4u && rd32(s + p - 4u) == rd32(s + p)) { best = common(s + p, s + p - 4u, cap8); bc = p - 4u; cand = 1; }
                 for (int k = (int)q; k >= 0; k--) {                   // nearest region first; a farther one must be strictly longer
                     const uint32_t d = e[k] - tb;
                     if (!((uint32_t)k < q ? d < 0x10000u : d < rel)) continue;
+                    cand = 1;
                     const uint32_t c = ((uint32_t)k << LZ4S_RLOG) + d;
                     const uint32_t l = common(s + p, s + c, cap8);
                     if (l >= 4u && l > best) { best = l; bc = c; }
                 }
+                if (cand) visits++;                                   // a position with a candidate by tag (or a period hit) is a visit of the lane
                 if (!best) { z.n_probe_fail++; continue; }            // tag hit that does not verify (or no candidate): a literal
                 uint32_t len = best;
                 if (len == 8u) {
@@ -141,7 +143,6 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
             op = o + lit;
         } else op += 1u + ext_bytes(lit) + lit;
     }
-    if (lz4s_dbg_recs) { memcpy(lz4s_dbg_recs, rec, LZ4S_LANES*16*4); memcpy(lz4s_dbg_nrec, nrec, LZ4S_LANES*4); }
     if (st) *st = z;
     free(T); free(rec); free(nrec);
     return op;

@@ -81,3 +81,20 @@ def test_emu_cdc_without_dedup():
     c = synth.dedup_stream(1 << 18).tobytes()
     prefix, seg_end, fps, first, base, _ = emulib.EmuCdc().run([c], G, dedup=False)
     assert first is None and (seg_end == ref.gear_cdc(c)).all()
+
+
+def test_emu_dedup_overfull_table_is_not_an_error():
+    """a fingerprint table that cannot take more segments must not stop the transfer.  2^10 slots against ~4000 distinct
+    segments: every call succeeds, a segment is either placed (first-seen index <= its own) or reported as not seen before."""
+    gear = ref.gear_table()
+    cdc = emulib.EmuCdc(slots_log2=10)
+    rng = synth.rng_for(3, 77)
+    seen_total = 0
+    for _ in range(4):
+        chunks = [synth.gen_random(rng, 4 << 20).tobytes() for _ in range(4)]
+        prefix, seg_end, fps, first, base, _ = cdc.run(chunks, gear, dedup=True)
+        n = int(prefix[-1])
+        idx = np.arange(base, base + n, dtype=np.uint64)
+        assert (first[:n] <= idx).all()
+        seen_total += n
+    assert seen_total > 3 * 1024
