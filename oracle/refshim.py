@@ -18,7 +18,8 @@ from pathlib import Path
 _REPO = Path(__file__).resolve().parents[1]
 # the read-only reference tree (build container) or, on the GPU box, the copy oracle/stage_reference.py staged under oracle/_ref/
 # (git-ignored, travels with gpurun)
-REFERENCE = Path("/root/reference") if Path("/root/reference/skyplane/chunk.py").is_file() else _REPO / "oracle" / "_ref"
+REFERENCE = (Path(os.environ["SKY_REFERENCE_ROOT"]) if os.environ.get("SKY_REFERENCE_ROOT") else
+             Path("/root/reference") if Path("/root/reference/skyplane/chunk.py").is_file() else _REPO / "oracle" / "_ref")
 
 
 def available() -> bool:

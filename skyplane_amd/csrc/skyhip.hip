@@ -428,7 +428,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             la.prof = nullptr;
             la.queue = c->d_queue.p;
 #if SKY_PROF
-            if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8)); }
+            if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 64 * 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 64 * 16 * 8)); }
             la.prof = c->d_prof;
 #endif
             SkyFrameArgs fa;
@@ -701,8 +701,10 @@ int skyhip_debug_prof(skyhip_ctx* c, uint64_t out[16]) {
     if (!c || !out) return SKYHIP_E_INVAL;
     memset(out, 0, 16 * 8);
     if (c->d_prof) {
-        HIPCHK(c, hipMemcpy(out, c->d_prof, 16 * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemset(c->d_prof, 0, 16 * 8));
+        uint64_t all[64 * 16];      // 64 copies (see the kernels): summed here
+        HIPCHK(c, hipMemcpy(all, c->d_prof, sizeof all, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemset(c->d_prof, 0, sizeof all));
+        for (int k = 0; k < 64; k++) for (int i = 0; i < 16; i++) out[i] += all[16 * k + i];
     }
     return SKYHIP_OK;
 }

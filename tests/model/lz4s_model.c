@@ -9,6 +9,9 @@
 #include <string.h>
 
 #include "lz4s_spec.h"
+#ifndef LZ4S_VISITS_MODEL
+#define LZ4S_VISITS_MODEL 12u
+#endif
 
 static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint32_t ext_bytes(uint32_t x) { return x < 15u ? 0u : 1u + (x - 15u) / 255u; }
@@ -28,6 +31,7 @@ typedef struct { uint32_t n_rec, n_kept, n_trimmed, n_dropped, n_probe_fail; } l
 
 // Compress one block of n <= 65536 bytes.  Returns the compressed size; writes the block when dst != NULL
 // (dst must hold n + n/255 + 16 bytes).  recs_out (optional, 16 * LZ4S_LANES words) receives the raw per-slice records.
+uint32_t* lz4s_dbg_visits = 0;   /* optional: LZ4S_LANES words, visits made per slice (load statistics for kernel tuning) */
 uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats* st) {
     const uint32_t NB = 1u << LZ4S_LOGB;
     uint32_t* T = (uint32_t*)malloc((size_t)NB * LZ4S_Q * 4);
@@ -51,7 +55,7 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
             const uint32_t s0 = j * LZ4S_SLICE, s1 = s0 + LZ4S_SLICE < n ? s0 + LZ4S_SLICE : n;
             const uint32_t lim = s1 + LZ4S_EXT < matchlimit ? s1 + LZ4S_EXT : matchlimit;
             uint32_t pos = s0, lanchor = s0, visits = 0;
-            for (uint32_t p = s0; p < s1 && p <= mflimit && visits < 16u; p++) {
+            for (uint32_t p = s0; p < s1 && p <= mflimit && visits < LZ4S_VISITS_MODEL; p++) {
                 if (p < pos) continue;
                 const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
                 const uint32_t q = p >> LZ4S_RLOG, tb = LZ4S_TAG(x) << 16, rel = p & ((1u << LZ4S_RLOG) - 1u);
@@ -89,6 +93,7 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                 z.n_rec++;
                 pos = mp + len; lanchor = pos;
             }
+            if (lz4s_dbg_visits) lz4s_dbg_visits[j] = visits;
         }
         // stitch: trim overlaps in slice order; a slice's first surviving match that continues the previous surviving match
         // (no literals in between, same offset) is merged into it; then emit
