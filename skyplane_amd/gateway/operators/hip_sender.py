@@ -44,6 +44,32 @@ def chunk_digest(chunk_store: ChunkStore, chunk_id: str) -> Optional[bytes]:
     return bytes.fromhex(p.read_text().strip()) if p.exists() else None
 
 
+def attach_digest(chunk_dict: dict, chunk_store: ChunkStore) -> dict:
+    """Source side of the checksum plumbing.  The sender pre-registers its chunks with the destination as
+    ``json.dumps([c.chunk.as_dict() ...])`` (gateway_operator.py:299); ``Chunk.md5_hash`` is declared bytes (chunk.py:21) and bytes do not
+    survive json.dumps, so the digest gpu_compress left in ``<id>.chunk.md5`` rides along as its hex string.  INTEGRATION.md section 7a."""
+    p = sidecar.digest_path(chunk_store, chunk_dict["chunk_id"])
+    if p.exists():
+        chunk_dict = dict(chunk_dict, md5_hash=p.read_text().strip())
+    return chunk_dict
+
+
+def verified_digest(chunk, chunk_store: ChunkStore) -> Optional[bytes]:
+    """Destination side: what ``GatewayObjStoreWriteOperator.process`` passes to
+    ``upload_object(check_md5=...)`` (gateway_operator.py:633-643).  The registered digest (hex, from the source GPU) is compared with
+    the digest of what actually arrived -- written next to the chunk by the receiver's `# todo check hash` edit or by gpu_decompress --
+    and returned as the 16 raw bytes the object stores expect (s3_interface.py:203 base64-encodes them into Content-MD5).  A mismatch
+    raises: the upload must not happen."""
+    want = chunk.md5_hash
+    if want is None:
+        return None
+    want = bytes.fromhex(want) if isinstance(want, str) else bytes(want)
+    got = chunk_digest(chunk_store, chunk.chunk_id)
+    if got is not None and got != want:
+        raise ValueError(f"[Gateway] chunk {chunk.chunk_id}: digest of the received bytes {got.hex()} differs from the digest the source registered {want.hex()}")
+    return want
+
+
 def cleanup_sidecars(chunk_store: ChunkStore, chunk_id: str):
     """gateway_daemon_api.py:125-127 unlinks only <id>.chunk; whoever completes the chunk removes the sidecars."""
     for p in (sidecar.compressed_path(chunk_store, chunk_id), sidecar.digest_path(chunk_store, chunk_id)):

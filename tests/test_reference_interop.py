@@ -25,6 +25,16 @@ def test_operator_is_a_drop_in_for_the_reference_classes():
     assert "OK dropin" in p.stdout
 
 
+def test_checksum_plumbing_and_planner_patches_run_against_the_reference():
+    """SURVEY 8f items 3 and 4 as executable patches (INTEGRATION.md sections 7 and 9): the sender's registration carries the GPU digest,
+    the write operator verifies it and hands upload_object the 16 raw bytes, a corrupted chunk is refused; MulticastDirectPlanner with
+    TransferConfig(use_gpu_compression=True) plans read -> gpu_compress -> mux_and -> mux_or -> send(compress=False)
+    (tests/_reference_f3f4.py applies the edits to the reference's source in memory and runs it)."""
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "_reference_f3f4.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, f"{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
+    assert "OK f3 chunks=3 f4 program=read_object_store>gpu_compress>mux_and>mux_or>send" in p.stdout
+
+
 @pytest.mark.parametrize("scenario", ["to_reference", "from_reference"])
 def test_interop_with_reference_gateway(scenario):
     from tests.emu import emulib
@@ -34,23 +44,29 @@ def test_interop_with_reference_gateway(scenario):
     assert f"OK {scenario}" in p.stdout
 
 
-def _run_daemon_harness(*args, timeout=240):
+def _run_daemon_harness(*args, timeout=150, attempts=3):
     """oracle/ref_daemon.py forks two reference daemons (which fork busy-spinning workers): own session, and the
-    whole group is killed if it overstays."""
+    whole group is killed if it overstays.  A run normally takes 5-10 s; on a small, busy box the reference's spinning
+    workers occasionally starve each other for minutes (VERDICT r1 weak #12), so an overstaying attempt is killed and retried."""
     import json
     import os
     import signal
+    import time
 
-    p = subprocess.Popen([sys.executable, str(ROOT / "oracle" / "ref_daemon.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                         start_new_session=True)
-    try:
-        out, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        os.killpg(p.pid, signal.SIGKILL)
-        out, err = p.communicate()
-        pytest.fail(f"daemon harness timed out\n{err[-3000:]}")
-    assert p.returncode == 0, f"{out[-2000:]}\n{err[-4000:]}"
-    return json.loads(out.strip().splitlines()[-1])
+    for attempt in range(attempts):
+        p = subprocess.Popen([sys.executable, str(ROOT / "oracle" / "ref_daemon.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+            if attempt + 1 < attempts:
+                time.sleep(2.0)         # let the kernel release the fixed ports
+                continue
+            pytest.fail(f"daemon harness timed out {attempts} times\n{err[-3000:]}")
+        assert p.returncode == 0, f"{out[-2000:]}\n{err[-4000:]}"
+        return json.loads(out.strip().splitlines()[-1])
 
 
 def test_reference_daemons_plain_and_with_gpu_compress_operator():
@@ -82,7 +98,7 @@ def test_wire_header_differential_against_reference_chunk_py():
 
     from skyplane_amd import chunk as mine
 
-    spec = importlib.util.spec_from_file_location("ref_chunk_diff", "/root/reference/skyplane/chunk.py")
+    spec = importlib.util.spec_from_file_location("ref_chunk_diff", str(refshim.REFERENCE / "skyplane" / "chunk.py"))
     theirs = importlib.util.module_from_spec(spec)
     sys.modules["ref_chunk_diff"] = theirs
     spec.loader.exec_module(theirs)
