@@ -363,6 +363,23 @@ def main():
             dup = first != np.arange(base, base + len(first), dtype=np.uint64)
             res["config"]["segments"] = int(len(first)); res["config"]["avg_segment_bytes"] = round(float(seg_len.mean()), 1)
             res["config"]["duplicate_bytes_fraction"] = round(float(seg_len[dup].sum() / seg_len.sum()), 4)
+            # the fraction the frozen CPU specification (oracle/skyoracle.c) finds on the same generator, next to the GPU's.  The
+            # specification is run on the first 64 MiB of tile 0 (the stream is that unit tiled; duplicates live inside a tile).
+            from oracle import ref
+
+            n_s = min(n_chunks, max(1, (64 << 20) // cb))
+            chunks_s = [np.concatenate(chunk_view(i, rots, True)) for i in range(n_s)]
+            fps, lens = [], []
+            for c in chunks_s:
+                st = 0
+                for e in ref.gear_cdc(c):
+                    fps.append(hashlib.md5(c[st:int(e)]).digest()); lens.append(int(e) - st); st = int(e)
+            first = ref.dedup_first(np.frombuffer(b"".join(fps), np.uint8).reshape(-1, 16))
+            lens = np.array(lens)
+            res["config"]["duplicate_bytes_fraction_cpu_spec"] = round(float(lens[first != np.arange(len(first))].sum() / lens.sum()), 4)
+            res["config"]["cpu_spec_sample"] = f"{n_s} chunks ({n_s * cb >> 20} MiB) of tile 0: oracle gear_cdc + md5 + first-seen"
+            g0 = int(prefix[n_s])
+            res["config"]["duplicate_bytes_fraction_same_sample_gpu"] = round(float(seg_len[:g0][dup[:g0]].sum() / seg_len[:g0].sum()), 4)
         if want_cpu:
             res["cpu_baseline"] = cpu_baseline(pool, cores, quota, rots, 12.0 if world == 1 else 6.0)
         print(json.dumps(res), flush=True)

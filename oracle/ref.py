@@ -137,9 +137,9 @@ def gear_table() -> np.ndarray:
 
 
 # Frozen CDC parameters (ours; not in the reference): 4 KiB / 16 KiB / 64 KiB, masks on high bits.
-CDC_MIN, CDC_AVG, CDC_MAX = 4096, 16384, 65536
-CDC_MASK_S = 0xFFFF000000000000  # 16 bits: harder, used before the average size
-CDC_MASK_L = 0xFFF0000000000000  # 12 bits: easier, used after it (subset of MASK_S)
+CDC_MIN, CDC_AVG, CDC_MAX = 1024, 4096, 16384
+CDC_MASK_S = 0xFFFC000000000000  # 14 bits: harder, used before the average size
+CDC_MASK_L = 0xFFC0000000000000  # 10 bits: easier, used after it (subset of MASK_S)
 
 
 def gear_cdc(data, min_size=CDC_MIN, avg_size=CDC_AVG, max_size=CDC_MAX, mask_s=CDC_MASK_S, mask_l=CDC_MASK_L) -> np.ndarray:

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import os
 import queue
+import threading
 import time
 import traceback
 from abc import ABC, abstractmethod
@@ -134,7 +135,7 @@ class GatewayHipCompress(GatewayOperator):
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
-                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None):
+                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
         self.max_batch = int(max_batch)
         self.max_chunk_bytes = int(max_chunk_bytes)
@@ -144,10 +145,43 @@ class GatewayHipCompress(GatewayOperator):
         self.dedup = dedup
         self.idle_sleep_s = idle_sleep_s
         self._context_factory = context_factory or _default_context_factory
-        self._ctx = None
-        self._arenas = {}
+        # Every worker process runs `pipeline_depth` lanes (threads), each with its own device context and pinned arenas.  A batch's
+        # whole-chunk MD5 is a serial chain of ~0.1 s per 8 MiB whatever the batch size: with one lane the worker would sit
+        # in that call while the next batch waits; with several, lane B uploads and compresses while lane A's chain runs (the C ABI is
+        # synchronous per context and ctypes releases the GIL, so lanes overlap on the device and in the kernel's file I/O).
+        self.pipeline_depth = max(1, int(pipeline_depth))
+        # a lane that finds fewer than max_batch requests waits this long once for more before it launches: trickling input otherwise
+        # turns into many one-chunk calls that each pay the full chain latency
+        self.fill_wait_s = float(fill_wait_s)
+        self._tls = threading.local()
 
     # -- process-local ---------------------------------------------------------------------------------
+    @property
+    def _ctx(self):
+        return getattr(self._tls, "ctx", None)
+
+    @_ctx.setter
+    def _ctx(self, v):
+        self._tls.ctx = v
+
+    @property
+    def _arenas(self):
+        if not hasattr(self._tls, "arenas"):
+            self._tls.arenas = {}
+        return self._tls.arenas
+
+    @_arenas.setter
+    def _arenas(self, v):
+        self._tls.arenas = v
+
+    @property
+    def _last_metadata(self):
+        return getattr(self._tls, "last_metadata", [])
+
+    @_last_metadata.setter
+    def _last_metadata(self, v):
+        self._tls.last_metadata = v
+
     def _context(self):
         if self._ctx is None:
             wid = self.worker_id or 0
@@ -230,16 +264,25 @@ class GatewayHipCompress(GatewayOperator):
     def process(self, chunk_req: ChunkRequest, **args):
         return self.process_batch([chunk_req])[0]
 
-    def worker_loop(self, worker_id: int, *args):
-        self.worker_id = worker_id
+    def _take_batch(self) -> List[ChunkRequest]:
+        batch: List[ChunkRequest] = []
+        waited = False
+        while len(batch) < self.max_batch:
+            try:
+                batch.append(self.input_queue.get_nowait(self.handle))
+            except queue.Empty:
+                if batch and not waited and self.fill_wait_s > 0:
+                    waited = True
+                    time.sleep(self.fill_wait_s)       # one short wait for stragglers, then go with what is there
+                    continue
+                break
+        return batch
+
+    def _lane_loop(self, worker_id: int):
+        """One pipeline lane: drain up to max_batch requests, one device call, hand the chunks on."""
         while not self.exit_flags[worker_id].is_set() and not self.error_event.is_set():
             try:
-                batch: List[ChunkRequest] = []
-                while len(batch) < self.max_batch:
-                    try:
-                        batch.append(self.input_queue.get_nowait(self.handle))
-                    except queue.Empty:
-                        break
+                batch = self._take_batch()
                 if not batch:
                     time.sleep(self.idle_sleep_s)      # no busy spin (reference :84-88 spins)
                     continue
@@ -263,7 +306,17 @@ class GatewayHipCompress(GatewayOperator):
                 self.error_queue.put(traceback.format_exc())
                 self.error_event.set()
                 self.exit_flags[worker_id].set()
-        self.worker_exit(worker_id)
+        self.worker_exit(worker_id)                    # this lane's context and arenas (thread-local)
+
+    def worker_loop(self, worker_id: int, *args):
+        self.worker_id = worker_id
+        lanes = [threading.Thread(target=self._lane_loop, args=(worker_id,), name=f"{self.handle}-w{worker_id}-lane{k}", daemon=True)
+                 for k in range(self.pipeline_depth - 1)]
+        for t in lanes:
+            t.start()
+        self._lane_loop(worker_id)                     # the worker's own thread is lane 0
+        for t in lanes:
+            t.join()
 
     def worker_exit(self, worker_id: int):
         if self._ctx is not None:

@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import SkyHipError, Timing
 
 F_LZ4, F_MD5, F_CDC, F_DEDUP = 1, 2, 4, 8
+CDC_MIN_SEGMENT = 1024      # SKY_CDC_MIN of csrc/gear_kernel.inc: a chunk of n bytes has at most n // CDC_MIN_SEGMENT + 2 cut points
 
 
 def frame_bound(raw_len: int) -> int:
@@ -115,7 +116,7 @@ class SkyHipContext:
         md5 = np.zeros((n, 16), np.uint8) if flags & F_MD5 else None
         cuts, cut_ptrs, cut_cap, n_cuts = [], None, None, None
         if flags & F_CDC:
-            cuts = [np.empty(a.size // 4096 + 2, np.uint32) for a in arrs]
+            cuts = [np.empty(a.size // CDC_MIN_SEGMENT + 2, np.uint32) for a in arrs]
             cut_ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in cuts])
             cut_cap = (C.c_size_t * n)(*[c.size for c in cuts])
             n_cuts = (C.c_size_t * n)()
@@ -192,7 +193,7 @@ class SkyHipContext:
 
     def cdc_results(self, n: int, in_len: np.ndarray):
         """CDC output of the last call with F_CDC: (cut_prefix[n+1], cuts, fingerprints[nseg,16], first_seen[nseg], seg_base)."""
-        cap = int(sum(int(l) // 4096 + 2 for l in in_len))
+        cap = int(sum(int(l) // CDC_MIN_SEGMENT + 2 for l in in_len))
         prefix = np.zeros(n + 1, np.uint64)
         cuts = np.zeros(max(cap, 1), np.uint32)
         fps = np.zeros((max(cap, 1), 16), np.uint8)

@@ -196,8 +196,8 @@ def dedup_stream(nbytes: int, dup_fraction: float = 0.5, config_id: int = 3, spa
         span = int(rng.integers(span_min, span_max + 1))
         span = min(span, nbytes - pos)
         if history and rng.random() < dup_fraction:
-            s, l = history[int(rng.integers(0, len(history)))]
-            l = min(l, span)
+            s, l = history[int(rng.integers(0, len(history)))]      # the WHOLE earlier span is pasted (up to the end of the stream)
+            l = min(l, nbytes - pos)
             out[pos:pos + l] = out[s:s + l]
             pos += l
         else:

@@ -131,7 +131,7 @@ class EmuCdc:
         n = len(chunks)
         lens = np.array([len(c) for c in chunks], np.uint64)
         in_off, in_addr, _keep_in = _pack_inputs(chunks, guard)
-        cap = int(sum(len(c) // 4096 + 2 for c in chunks))
+        cap = int(sum(len(c) // 1024 + 2 for c in chunks))
         prefix = np.zeros(n + 1, np.uint32)
         seg_end = np.zeros(cap, np.uint32)
         fps = np.zeros((cap, 16), np.uint8)
