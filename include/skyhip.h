@@ -46,7 +46,7 @@ extern "C" {
 #define SKYHIP_E_TOOBIG     -4   /* chunk larger than max_chunk_bytes / batch larger than supported */
 #define SKYHIP_E_CAP        -5   /* an output buffer is smaller than skyhip_frame_bound(len) / cut capacity */
 #define SKYHIP_E_NODEVICE   -6   /* no usable gfx950 device */
-#define SKYHIP_E_TABLEFULL  -7   /* dedup table is full */
+#define SKYHIP_E_TABLEFULL  -7   /* (no longer returned: a full dedup table is aged, segments that find no slot are reported as new) */
 #define SKYHIP_E_FORMAT     -8   /* a frame handed to skyhip_decompress_* is malformed or uses an unsupported option */
 
 typedef struct skyhip_ctx skyhip_ctx;   /* opaque: owns device scratch, streams, events, dedup table */
@@ -149,9 +149,12 @@ int  skyhip_selftest(skyhip_ctx* ctx);
 
 /* Development aid: accumulated in-kernel phase timers of a -DSKY_PROF=1 build (all zeros in the shipping build). */
 int  skyhip_debug_prof(skyhip_ctx* ctx, uint64_t out[16]);
+/* test hook: make the (n+1)-th checked HIP call of this context fail (n < 0: off); the failing call returns SKYHIP_E_HIP and
+   must leave the context usable */
+int  skyhip_debug_fault(skyhip_ctx* ctx, long n);
 
 const char* skyhip_strerror(int code);
-const char* skyhip_last_hip_error(skyhip_ctx* ctx);   /* hipGetErrorString of the last failing HIP call */
+const char* skyhip_last_hip_error(skyhip_ctx* ctx);   /* hipGetErrorString of the last failing HIP call; ctx == NULL: of this thread's last failed skyhip_create */
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ EXPORTS = (
     "skyhip_abi_version", "skyhip_create", "skyhip_destroy", "skyhip_frame_bound", "skyhip_process_batch", "skyhip_process_device",
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
-    "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5",
+    "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault",
 )
 
 
@@ -75,6 +75,8 @@ def load() -> C.CDLL:
     lib.skyhip_get_timing.restype = None
     lib.skyhip_reset_timing.argtypes = [vp]
     lib.skyhip_reset_timing.restype = None
+    lib.skyhip_debug_fault.argtypes = [vp, C.c_long]
+    lib.skyhip_debug_fault.restype = C.c_int
     lib.skyhip_selftest.argtypes = [vp]
     lib.skyhip_selftest.restype = C.c_int
     lib.skyhip_decompress_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -168,9 +168,10 @@ struct skyhip_ctx {
     SkyLz4dState dec;   // frame decompressor state
     double dec_ms = 0;
     // timing
-    std::vector<EvPair> ev_busy, ev_free;
+    std::vector<EvPair> ev_busy, ev_free, ev_open;     // open = begun, not ended yet (returned to ev_free if a call bails out in between)
     skyhip_timing tm;
     char hip_err[256];
+    long fault_after = -1;        // skyhip_debug_fault: the (n+1)-th checked HIP call from now fails artificially (error-path tests); -1 = off
     uint32_t* d_self = nullptr;
     sky_u64* d_prof = nullptr;   // SKY_PROF builds only
 };
@@ -178,6 +179,7 @@ struct skyhip_ctx {
 #define HIPCHK(ctx, expr)                                                                             \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
+        if (_e == hipSuccess && (ctx)->fault_after >= 0 && (ctx)->fault_after-- == 0) _e = hipErrorUnknown;   /* skyhip_debug_fault (tests) */ \
         if (_e != hipSuccess) {                                                                       \
             snprintf((ctx)->hip_err, sizeof((ctx)->hip_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             return _e == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP;                         \
@@ -189,15 +191,40 @@ static int ev_begin(skyhip_ctx* c, hipStream_t s, int kind, EvPair* out) {
     if (!c->ev_free.empty()) { p = c->ev_free.back(); c->ev_free.pop_back(); }
     else { HIPCHK(c, hipEventCreate(&p.a)); HIPCHK(c, hipEventCreate(&p.b)); }
     p.kind = kind;
+    c->ev_open.push_back(p);
     HIPCHK(c, hipEventRecord(p.a, s));
     *out = p;
     return 0;
 }
 static int ev_end(skyhip_ctx* c, hipStream_t s, EvPair& p) {
     HIPCHK(c, hipEventRecord(p.b, s));
+    for (size_t i = 0; i < c->ev_open.size(); i++)
+        if (c->ev_open[i].a == p.a) { c->ev_open.erase(c->ev_open.begin() + (long)i); break; }
     c->ev_busy.push_back(p);
     return 0;
 }
+static void ev_collect_free(skyhip_ctx* c) {      // error path: recorded pairs are recycled without being accounted
+    for (auto& p : c->ev_busy) c->ev_free.push_back(p);
+    c->ev_busy.clear();
+}
+// scope guard of a call that uses ev_begin/ev_end: whatever is still open when the call returns (an error path between
+// the two) is recycled instead of stranded
+struct EvOpenGuard {
+    skyhip_ctx* c;
+    bool ok = false;      // set by the call's successful end
+    ~EvOpenGuard() {
+        if (!ok) {        // bailing out with work possibly in flight: nothing may still touch the caller's or the context's buffers
+            for (hipStream_t st : {c->s_lz4, c->s_md5, c->s_cdc, c->s_up, c->s_down}) if (st) (void)hipStreamSynchronize(st);
+            ev_collect_free(c);
+        }
+        for (auto& p : c->ev_open) c->ev_free.push_back(p);
+        c->ev_open.clear();
+    }
+};
+struct EventOwner {       // a one-off event that must not outlive the call, whichever way the call ends
+    hipEvent_t e = nullptr;
+    ~EventOwner() { if (e) (void)hipEventDestroy(e); }
+};
 static void ev_collect(skyhip_ctx* c) {
     for (auto& p : c->ev_busy) {
         float ms = 0.f;
@@ -239,7 +266,8 @@ const char* skyhip_strerror(int code) {
     }
 }
 
-const char* skyhip_last_hip_error(skyhip_ctx* ctx) { return ctx ? ctx->hip_err : ""; }
+static thread_local char g_create_err[256] = "";     // what went wrong in the last failed skyhip_create of this thread (there is no context to ask)
+const char* skyhip_last_hip_error(skyhip_ctx* ctx) { return ctx ? ctx->hip_err : g_create_err; }
 
 int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_ctx** out) {
     if (!out || max_batch <= 0 || max_chunk_bytes == 0 || max_chunk_bytes > ((size_t)1 << 30)) return SKYHIP_E_INVAL;
@@ -292,7 +320,8 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         }
         return 0;
     }();
-    if (rc) { skyhip_destroy(c); return rc; }
+    if (rc) { snprintf(g_create_err, sizeof g_create_err, "%s", c->hip_err); skyhip_destroy(c); return rc; }
+    g_create_err[0] = 0;
     *out = c;
     return SKYHIP_OK;
 }
@@ -306,6 +335,8 @@ void skyhip_destroy(skyhip_ctx* c) {
     if (c->s_up) (void)hipStreamSynchronize(c->s_up);
     if (c->s_down) (void)hipStreamSynchronize(c->s_down);
     ev_collect(c);
+    for (auto& p : c->ev_open) c->ev_free.push_back(p);
+    c->ev_open.clear();
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
@@ -374,8 +405,10 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
     HIPCHK(c, hipMemcpyAsync(c->d_in_len.p, c->h_in_len.p, N * 4, hipMemcpyHostToDevice, c->s_lz4));
     HIPCHK(c, hipMemcpyAsync(c->d_out_off.p, c->h_out_off.p, N * 8, hipMemcpyHostToDevice, c->s_lz4));
     HIPCHK(c, hipMemcpyAsync(c->d_blk_prefix.p, c->h_blk_prefix.p, (N + 1) * 4, hipMemcpyHostToDevice, c->s_lz4));
-    hipEvent_t meta_ready;
-    HIPCHK(c, hipEventCreateWithFlags(&meta_ready, hipEventDisableTiming));
+    EvOpenGuard open_guard{c};
+    EventOwner meta_owner;
+    HIPCHK(c, hipEventCreateWithFlags(&meta_owner.e, hipEventDisableTiming));
+    const hipEvent_t meta_ready = meta_owner.e;
     HIPCHK(c, hipEventRecord(meta_ready, c->s_lz4));
 
     int rc = 0;
@@ -478,7 +511,6 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
     HIPCHK(c, hipStreamSynchronize(c->s_lz4));
     HIPCHK(c, hipStreamSynchronize(c->s_md5));
     HIPCHK(c, hipStreamSynchronize(c->s_cdc));
-    (void)hipEventDestroy(meta_ready);
     ev_collect(c);
 #ifdef SKY_WITH_CDC
     if (flags & SKYHIP_F_CDC) { int frc = sky_cdc_finish(&c->cdc); if (frc) return frc; }
@@ -490,6 +522,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         }
     }
     if ((flags & SKYHIP_F_MD5) && md5) memcpy(md5, c->h_md5.p, 16 * N);
+    open_guard.ok = true;
     return SKYHIP_OK;
 }
 
@@ -706,6 +739,14 @@ int skyhip_debug_prof(skyhip_ctx* c, uint64_t out[16]) {
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof all));
         for (int k = 0; k < 64; k++) for (int i = 0; i < 16; i++) out[i] += all[16 * k + i];
     }
+    return SKYHIP_OK;
+}
+
+// test hook: the (n+1)-th checked HIP call of this context fails with hipErrorUnknown (n < 0 switches it off).  Exercises the
+// early-return paths of the calls above, which must leave the context usable (tests/test_gpu_parity.py).
+int skyhip_debug_fault(skyhip_ctx* c, long n) {
+    if (!c) return SKYHIP_E_INVAL;
+    c->fault_after = n;
     return SKYHIP_OK;
 }
 

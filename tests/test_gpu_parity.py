@@ -299,3 +299,34 @@ def test_host_batch_pinned_buffers_and_pipelined_sub_batches(monkeypatch):
         c.release_pinned(arena_in)
         with pytest.raises(hip_ops.SkyHipError):
             c._check(c._lib.skyhip_host_free(c._h, 12345))          # not one of ours
+
+
+def test_error_paths_leave_the_context_usable(ctx):
+    """early returns of the C ABI (capacity errors, malformed frames) must not strand events or leave work in flight --
+    provoke each a few dozen times, then the same context must still produce correct results."""
+    from skyplane_amd import hip_ops
+    d = synth.gen_text(synth.rng_for(5), 300_000).tobytes()
+    small = np.empty(1000, np.uint8)                      # far below skyhip_frame_bound
+    for _ in range(40):
+        with pytest.raises(hip_ops.SkyHipError):
+            ctx.process_batch([d, d, d], frames_into=[small, small, small])
+        with pytest.raises((hip_ops.SkyHipError, ValueError)):
+            ctx.decompress_batch([b"\x04\x22\x4d\x18garbage-not-a-frame", ref.lz4f_compress(d)[:-7]], [100, len(d)])
+    # every checked HIP call of a host-buffer batch fails once (skyhip_debug_fault): the call reports an error, the next one is correct
+    chunks = [d, d[:70_001], b"", d[::-1]]
+    failed = 0
+    for n in range(0, 400, 3):
+        ctx._lib.skyhip_debug_fault(ctx._h, n)
+        try:
+            res = ctx.process_batch(chunks)
+        except hip_ops.SkyHipError:
+            failed += 1
+            ctx._lib.skyhip_debug_fault(ctx._h, -1)
+            _check(chunks, ctx.process_batch(chunks))
+            continue
+        ctx._lib.skyhip_debug_fault(ctx._h, -1)
+        _check(chunks, res)          # the countdown outlived the call: nothing failed, and from here on nothing will
+        break
+    assert failed >= 10, failed
+    _check([d, b"", d[:70_001]], ctx.process_batch([d, b"", d[:70_001]]))
+    assert ctx.decompress_batch([ref.lz4f_compress(d)], [len(d)]) == [d]
