@@ -306,7 +306,12 @@ def main():
                 break
             time.sleep(0.05)
         wall = time.time() - t0
-        assert done == len(chunks), f"{done} of {len(chunks)} chunks completed"
+        res["completed_chunks"] = done
+        if done < len(chunks):
+            # out of time: report what the DAG managed (a rate over the completed chunks) instead of nothing
+            res.update({"wall_s": round(wall, 3), "gbit_s": round(done * size * 8 / wall / 1e9, 3), "gib_s": round(done * size / wall / 2**30, 4),
+                        "verified": False, "timed_out": True})
+            raise TimeoutError(f"{done} of {len(chunks)} chunks completed in {wall:.0f} s")
         for cid, (path, dig) in datas.items():
             assert hashlib.md5(Path(path).read_bytes()).digest() == dig, path
         if a.gpu_op:
@@ -321,16 +326,20 @@ def main():
         ok = True
     finally:
         stop.set()
-        if not ok or a.keep_logs:
-            for n in ("src.log", "dst.log"):
-                if (work / n).exists():
-                    sys.stderr.write(f"---- {n} (tail) ----\n" + (work / n).read_text()[-3000:] + "\n")
-        line = json.dumps(res)
-        print(line, flush=True)
-        if a.out and ok:
-            Path(a.out).write_text(line + "\n")
-        shutil.rmtree(work, ignore_errors=True)
-        _reap_group()
+        try:
+            if not ok or a.keep_logs:
+                for n in ("src.log", "dst.log"):
+                    if (work / n).exists():
+                        with open(work / n, "rb") as f:
+                            f.seek(max(0, (work / n).stat().st_size - 3000))
+                            sys.stderr.write(f"---- {n} (tail) ----\n" + f.read().decode("utf-8", "replace") + "\n")
+            line = json.dumps(res)
+            print(line, flush=True)
+            if a.out and (ok or res.get("timed_out")):
+                Path(a.out).write_text(line + "\n")
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+            _reap_group()
     os._exit(0 if ok else 1)       # not sys.exit: multiprocessing's atexit hook would try to join the (killed) daemons
 
 
