@@ -29,11 +29,17 @@ extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compres
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_compress_body(a, smem);
 }
-extern "C" __global__ void __launch_bounds__(LZ4S_LANES) sky_lz4s_compress(SkyLz4Args a) {
+#ifndef LZ4S_KERNEL_ATTR
+#define LZ4S_KERNEL_ATTR      // experiment hook: e.g. -DLZ4S_KERNEL_ATTR='__attribute__((amdgpu_num_vgpr(96)))'
+#endif
+extern "C" __global__ void __launch_bounds__(LZ4S_LANES) LZ4S_KERNEL_ATTR sky_lz4s_compress(SkyLz4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4s_compress_body(a, smem);
 }
-extern "C" __global__ void __launch_bounds__(256) sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
+#ifndef SKY_MD5_KERNEL_ATTR
+#define SKY_MD5_KERNEL_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(256) SKY_MD5_KERNEL_ATTR sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }

@@ -66,13 +66,14 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                 // short-period candidate (runs, "abab", 32-bit patterns): the 4 bytes before p repeat at p.  Overlapping
                 // copies run as long as the period holds, which no table entry (the EARLIEST occurrence) can offer.
                 if (p >= 4u && rd32(s + p - 4u) == rd32(s + p)) { best = common(s + p, s + p - 4u, cap8); bc = p - 4u; cand = 1; }
+                // best = the longest of the candidates, ties to the nearest (largest position)
                 for (int k = (int)q; k >= 0; k--) {                   // nearest region first; a farther one must be strictly longer
                     const uint32_t d = e[k] - tb;
                     if (!((uint32_t)k < q ? d < 0x10000u : d < rel)) continue;
                     cand = 1;
                     const uint32_t c = ((uint32_t)k << LZ4S_RLOG) + d;
                     const uint32_t l = common(s + p, s + c, cap8);
-                    if (l >= 4u && l > best) { best = l; bc = c; }
+                    if (l >= 4u && (l > best || (l == best && c > bc))) { best = l; bc = c; }
                 }
                 if (cand) visits++;                                   // a position with a candidate by tag (or a period hit) is a visit of the lane
                 if (!best) { z.n_probe_fail++; continue; }            // tag hit that does not verify (or no candidate): a literal
