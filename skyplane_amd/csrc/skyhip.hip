@@ -160,6 +160,7 @@ struct skyhip_ctx {
     int md5_wg = 64;              // lanes per MD5 workgroup.  One wave per CU is as fast as MD5 gets: every lane streams its own chunk (64 cache lines per
                                   // load instruction), and a CU's memory path serves one such wave at full chain speed -- 2048 chunks take 98 ms as 64-lane
                                   // workgroups, 187 ms as 256-lane, 374 ms as 512-lane ones (profiles/r2_md5_workgroup.txt).  SKYHIP_MD5_WG overrides.
+    bool md5_wg_env = false;      // SKYHIP_MD5_WG given: no automatic choice
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
     bool lz4_wave_kernel = false; // SKYHIP_LZ4_KERNEL=wave: the round-1 wave-per-block compressor (kept for A/B measurements)
     DevBuf<sky_u64> d_blk_dst;
@@ -306,7 +307,7 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
         HIPCHK(c, c->d_queue.ensure(16));
-        { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) c->md5_wg = v; }
+        { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) { c->md5_wg = v; c->md5_wg_env = true; } }
         { const char* e = getenv("SKYHIP_LZ4_KERNEL"); c->lz4_wave_kernel = e && !strcmp(e, "wave"); }
 #ifdef SKY_WITH_CDC
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
@@ -428,7 +429,10 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         ma.in = (const uint8_t*)d_in; ma.off = c->d_in_off.p; ma.len = c->d_in_len.p; ma.n = (uint32_t)N; ma.digest = c->d_md5.p;
         EvPair ep;
         if ((rc = ev_begin(c, c->s_md5, K_MD5, &ep))) return rc;
-        hipLaunchKernelGGL(sky_md5_chunks, dim3((unsigned)((N + (size_t)c->md5_wg - 1) / (size_t)c->md5_wg)), dim3((unsigned)c->md5_wg), 0, c->s_md5, ma);
+        // one wave per CU is the fastest placement (82 ms per 8 MiB); two per CU cost 13 % of chain speed but leave twice as many CUs to the compressor,
+        // whose workgroups need a CU's whole register file: worth it once the digests alone would take more than a quarter of the chip
+        const int wg = (c->md5_wg_env || N <= (size_t)16 * c->lz4s_grid) ? c->md5_wg : 128;
+        hipLaunchKernelGGL(sky_md5_chunks, dim3((unsigned)((N + (size_t)wg - 1) / (size_t)wg)), dim3((unsigned)wg), 0, c->s_md5, ma);
         HIPCHK(c, hipGetLastError());
         if ((rc = ev_end(c, c->s_md5, ep))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->h_md5.p, c->d_md5.p, 16 * N, hipMemcpyDeviceToHost, c->s_md5));
