@@ -224,7 +224,7 @@ def main():
     n_chunks = n_target
     if not emu:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
-        scratch = args.max_batch * 128 * 66048
+        scratch = 2 * args.max_batch * 128 * 66048          # the library double-buffers its block scratch
         while n_chunks > 64 and n_chunks * cb + (n_chunks // halves) * stride + scratch + (6 << 30) > free_b:
             n_chunks //= 2
     if world > 1:   # every rank processes the same number of chunks (weak scaling: value = world x chunks x bytes / time)

@@ -145,7 +145,7 @@ struct skyhip_ctx {
     size_t max_chunk = 0;
     int max_batch = 0;
     uint32_t blocks_per_chunk = 0;
-    hipStream_t s_lz4 = nullptr, s_md5 = nullptr, s_cdc = nullptr;
+    hipStream_t s_lz4 = nullptr, s_md5 = nullptr, s_cdc = nullptr, s_fr = nullptr;     // s_fr: frame layout + gather of sub-batch k beside the compressor on k+1
     // per-chunk metadata (whole batch)
     DevBuf<sky_u64> d_in_off, d_out_off, d_frame_len;
     DevBuf<uint32_t> d_in_len, d_blk_prefix;
@@ -154,8 +154,10 @@ struct skyhip_ctx {
     PinBuf<uint32_t> h_in_len, h_blk_prefix;
     PinBuf<uint8_t> h_md5;
     // per-block data for one sub-batch
-    DevBuf<uint8_t> d_scratch;
-    DevBuf<uint32_t> d_csize, d_blk_word;
+    // block scratch, double buffered: sub-batch k compresses into buffer k & 1 while the frames of k-1 are assembled out of the other one
+    DevBuf<uint8_t> d_scratch[2];
+    DevBuf<uint32_t> d_csize[2], d_blk_word[2];
+    hipEvent_t ev_lz4_done[2] = {nullptr, nullptr}, ev_fr_done[2] = {nullptr, nullptr};
     DevBuf<uint32_t> d_queue;     // slice-parallel compressor: block queue head
     int md5_wg = 64;              // lanes per MD5 workgroup.  One wave per CU is as fast as MD5 gets: every lane streams its own chunk (64 cache lines per
                                   // load instruction), and a CU's memory path serves one such wave at full chain speed -- 2048 chunks take 98 ms as 64-lane
@@ -163,7 +165,7 @@ struct skyhip_ctx {
     bool md5_wg_env = false;      // SKYHIP_MD5_WG given: no automatic choice
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
     bool lz4_wave_kernel = false; // SKYHIP_LZ4_KERNEL=wave: the round-1 wave-per-block compressor (kept for A/B measurements)
-    DevBuf<sky_u64> d_blk_dst;
+    DevBuf<sky_u64> d_blk_dst[2];
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
     DevBuf<uint8_t> d_stage_in, d_stage_out;
     hipStream_t s_up = nullptr, s_down = nullptr;
@@ -221,7 +223,7 @@ struct EvOpenGuard {
     bool ok = false;      // set by the call's successful end
     ~EvOpenGuard() {
         if (!ok) {        // bailing out with work possibly in flight: nothing may still touch the caller's or the context's buffers
-            for (hipStream_t st : {c->s_lz4, c->s_md5, c->s_cdc, c->s_up, c->s_down}) if (st) (void)hipStreamSynchronize(st);
+            for (hipStream_t st : {c->s_lz4, c->s_fr, c->s_md5, c->s_cdc, c->s_up, c->s_down}) if (st) (void)hipStreamSynchronize(st);
             ev_collect_free(c);
         }
         for (auto& p : c->ev_open) c->ev_free.push_back(p);
@@ -293,15 +295,19 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
     int rc = [&]() -> int {
         HIPCHK(c, hipSetDevice(device_id));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_lz4, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_lz4_done[k], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fr_done[k], hipEventDisableTiming)); }
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_md5, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_cdc, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
         const size_t nb = (size_t)max_batch * c->blocks_per_chunk;
-        HIPCHK(c, c->d_scratch.ensure(nb * SKY_LZ4_SLOT));
-        HIPCHK(c, c->d_csize.ensure(nb));
-        HIPCHK(c, c->d_blk_word.ensure(nb));
-        HIPCHK(c, c->d_blk_dst.ensure(nb));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(c, c->d_scratch[k].ensure(nb * SKY_LZ4_SLOT));
+            HIPCHK(c, c->d_csize[k].ensure(nb));
+            HIPCHK(c, c->d_blk_word[k].ensure(nb));
+            HIPCHK(c, c->d_blk_dst[k].ensure(nb));
+        }
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_compress, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -337,6 +343,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
     if (c->s_lz4) (void)hipStreamSynchronize(c->s_lz4);
+    if (c->s_fr) (void)hipStreamSynchronize(c->s_fr);
     if (c->s_md5) (void)hipStreamSynchronize(c->s_md5);
     if (c->s_cdc) (void)hipStreamSynchronize(c->s_cdc);
     if (c->s_up) (void)hipStreamSynchronize(c->s_up);
@@ -347,7 +354,12 @@ void skyhip_destroy(skyhip_ctx* c) {
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_in_off.release(); c->d_out_off.release(); c->d_frame_len.release(); c->d_in_len.release(); c->d_blk_prefix.release(); c->d_md5.release();
     c->h_in_off.release(); c->h_out_off.release(); c->h_frame_len.release(); c->h_in_len.release(); c->h_blk_prefix.release(); c->h_md5.release();
-    c->d_scratch.release(); c->d_csize.release(); c->d_blk_word.release(); c->d_blk_dst.release(); c->d_queue.release();
+    for (int k = 0; k < 2; k++) {
+        c->d_scratch[k].release(); c->d_csize[k].release(); c->d_blk_word[k].release(); c->d_blk_dst[k].release();
+        if (c->ev_lz4_done[k]) (void)hipEventDestroy(c->ev_lz4_done[k]);
+        if (c->ev_fr_done[k]) (void)hipEventDestroy(c->ev_fr_done[k]);
+    }
+    c->d_queue.release();
     c->d_stage_in.release(); c->d_stage_out.release();
     for (hipEvent_t e : c->ev_up) (void)hipEventDestroy(e);
     c->ev_up.clear();
@@ -360,6 +372,7 @@ void skyhip_destroy(skyhip_ctx* c) {
     if (c->d_self) (void)hipFree(c->d_self);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->s_lz4) (void)hipStreamDestroy(c->s_lz4);
+    if (c->s_fr) (void)hipStreamDestroy(c->s_fr);
     if (c->s_md5) (void)hipStreamDestroy(c->s_md5);
     if (c->s_cdc) (void)hipStreamDestroy(c->s_cdc);
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
@@ -453,9 +466,12 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         if ((rc = ev_end(c, c->s_cdc, ep))) return rc;
 #endif
     }
-    // ---- LZ4: sub-batches of max_batch chunks share the block scratch ----
+    // ---- LZ4: sub-batches of max_batch chunks; the compressor (s_lz4) writes block scratch k & 1 while the frames of sub-batch k-1 are laid out
+    //      and gathered out of the other buffer on s_fr ----
     if (flags & SKYHIP_F_LZ4) {
-        for (size_t c0 = 0; c0 < N; c0 += (size_t)c->max_batch) {
+        size_t sub = 0;
+        for (size_t c0 = 0; c0 < N; c0 += (size_t)c->max_batch, sub++) {
+            const int bf = (int)(sub & 1);
             const size_t nc = (N - c0 < (size_t)c->max_batch) ? N - c0 : (size_t)c->max_batch;
             const uint32_t nb = c->h_blk_prefix.p[c0 + nc] - c->h_blk_prefix.p[c0];
             if (pipe) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, pipe->ev_up[c0 / (size_t)c->max_batch], 0));
@@ -463,7 +479,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             for (size_t i = c0; i < c0 + nc; i++) sub_bytes += c->h_in_len.p[i];
             SkyLz4Args la;
             la.in = (const uint8_t*)d_in; la.in_off = c->d_in_off.p + c0; la.in_len = c->d_in_len.p + c0; la.blk_prefix = c->d_blk_prefix.p + c0;
-            la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch.p; la.csize = c->d_csize.p;
+            la.n_chunks = (uint32_t)nc; la.n_blocks = nb; la.scratch = c->d_scratch[bf].p; la.csize = c->d_csize[bf].p;
             la.ablate = 0;
 #if SKY_ABL
             { const char* ab = getenv("SKYHIP_ABLATE"); la.ablate = ab ? (uint32_t)atoi(ab) : 0u; }   // timing-experiment builds only
@@ -476,10 +492,11 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
 #endif
             SkyFrameArgs fa;
             fa.in = la.in; fa.in_off = la.in_off; fa.in_len = la.in_len; fa.blk_prefix = la.blk_prefix; fa.n_chunks = la.n_chunks; fa.n_blocks = nb;
-            fa.scratch = c->d_scratch.p; fa.csize = c->d_csize.p; fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p + c0;
-            fa.frame_len = c->d_frame_len.p + c0; fa.blk_dst = c->d_blk_dst.p; fa.blk_word = c->d_blk_word.p;
+            fa.scratch = c->d_scratch[bf].p; fa.csize = c->d_csize[bf].p; fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p + c0;
+            fa.frame_len = c->d_frame_len.p + c0; fa.blk_dst = c->d_blk_dst[bf].p; fa.blk_word = c->d_blk_word[bf].p;
             EvPair ep;
             if (nb) {
+                if (sub >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, c->ev_fr_done[bf], 0));     // the frames of sub-batch sub-2 have left this buffer
                 if (!c->lz4_wave_kernel) HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4, c->s_lz4));     // block queue head
                 if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
                 if (c->lz4_wave_kernel) hipLaunchKernelGGL(sky_lz4_compress, dim3((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES), dim3(SKY_LZ4_WAVES * 64), SKY_LZ4_LDS_BYTES, c->s_lz4, la);
@@ -488,25 +505,28 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
                 if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
                 c->tm.lz4_launches++; c->tm.lz4_in_bytes += sub_bytes;
             }
-            if ((rc = ev_begin(c, c->s_lz4, K_LAYOUT, &ep))) return rc;
-            hipLaunchKernelGGL(sky_frame_layout, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, c->s_lz4, fa);
+            HIPCHK(c, hipEventRecord(c->ev_lz4_done[bf], c->s_lz4));
+            HIPCHK(c, hipStreamWaitEvent(c->s_fr, c->ev_lz4_done[bf], 0));      // (also orders s_fr behind the metadata upload on s_lz4)
+            if ((rc = ev_begin(c, c->s_fr, K_LAYOUT, &ep))) return rc;
+            hipLaunchKernelGGL(sky_frame_layout, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, c->s_fr, fa);
             HIPCHK(c, hipGetLastError());
-            if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+            if ((rc = ev_end(c, c->s_fr, ep))) return rc;
             if (nb) {
-                if ((rc = ev_begin(c, c->s_lz4, K_GATHER, &ep))) return rc;
-                hipLaunchKernelGGL(sky_frame_gather, dim3(nb), dim3(256), 0, c->s_lz4, fa);
+                if ((rc = ev_begin(c, c->s_fr, K_GATHER, &ep))) return rc;
+                hipLaunchKernelGGL(sky_frame_gather, dim3(nb), dim3(256), 0, c->s_fr, fa);
                 HIPCHK(c, hipGetLastError());
-                if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+                if ((rc = ev_end(c, c->s_fr, ep))) return rc;
             }
+            HIPCHK(c, hipEventRecord(c->ev_fr_done[bf], c->s_fr));
             if (pipe) {
-                HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p + c0, c->d_frame_len.p + c0, nc * 8, hipMemcpyDeviceToHost, c->s_lz4));
+                HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p + c0, c->d_frame_len.p + c0, nc * 8, hipMemcpyDeviceToHost, c->s_fr));
                 hipEvent_t e;
                 HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 ev_done.push_back(e);
-                HIPCHK(c, hipEventRecord(e, c->s_lz4));
+                HIPCHK(c, hipEventRecord(e, c->s_fr));
             }
         }
-        if (!pipe) HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_lz4));
+        if (!pipe) HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_fr));
         // pipe mode: ship each sub-batch's frames as soon as their lengths are known; later sub-batches keep computing
         for (size_t sidx = 0; sidx < ev_done.size(); sidx++) {
             HIPCHK(c, hipEventSynchronize(ev_done[sidx]));
@@ -519,6 +539,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    HIPCHK(c, hipStreamSynchronize(c->s_fr));
     HIPCHK(c, hipStreamSynchronize(c->s_md5));
     HIPCHK(c, hipStreamSynchronize(c->s_cdc));
     ev_collect(c);
