@@ -30,14 +30,17 @@ extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compres
     sky_lz4_compress_body(a, smem);
 }
 #ifndef LZ4S_KERNEL_ATTR
-#define LZ4S_KERNEL_ATTR      // experiment hook: e.g. -DLZ4S_KERNEL_ATTR='__attribute__((amdgpu_num_vgpr(96)))'
+// 5 waves per SIMD = 96 VGPRs: a compressor workgroup puts 4 waves on every SIMD of its CU, so one more wave of another kernel (MD5, frame
+// gather) fits beside it.  At the 128 VGPRs the launch bound alone would allow, the compressor runs 3 % faster alone but nothing else can
+// enter a CU it holds: the step of the bench went from 265 to 239 ms with this attribute (profiles/r2_coexist_ab.txt).
+#define LZ4S_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 extern "C" __global__ void __launch_bounds__(LZ4S_LANES) LZ4S_KERNEL_ATTR sky_lz4s_compress(SkyLz4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4s_compress_body(a, smem);
 }
 #ifndef SKY_MD5_KERNEL_ATTR
-#define SKY_MD5_KERNEL_ATTR
+#define SKY_MD5_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: fits in what four compressor waves leave of a SIMD
 #endif
 extern "C" __global__ void __launch_bounds__(256) SKY_MD5_KERNEL_ATTR sky_md5_chunks(SkyMd5Args a) { sky_md5_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
