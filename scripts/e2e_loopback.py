@@ -134,10 +134,8 @@ def main():
                     # source operator computed riding along as a JSON-safe hex string
                     dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
                     dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
-                    header, payload = hip_sender.wire_payload(src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
-                    header.to_socket(sock)
-                    sock.sendall(payload)
-                    wire[k] += len(payload)
+                    n_sent = hip_sender.send_chunk(sock, src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
+                    wire[k] += n_sent
 
         t0 = time.perf_counter()
         for cr in reqs:

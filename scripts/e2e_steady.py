@@ -62,6 +62,44 @@ def emu_context_factory(device_id, max_chunk_bytes, max_batch):
     return EmuContext()
 
 
+def null_context_factory(device_id, max_chunk_bytes, max_batch):
+    """Plumbing-only stand-in (--context null): "frames" are the raw bytes behind a 16-byte tag, digests are zeros, one memcpy each way.
+    What is left is the cost of everything around the device: files, queues, sockets, Python.  Not a correctness run."""
+    import numpy as np
+    from skyplane_amd.hip_ops import ChunkResult
+
+    class NullContext:
+        def pinned_buffer(self, n):
+            return np.empty(n, np.uint8)
+
+        def release_pinned(self, a):
+            pass
+
+        def frame_bound(self, n):
+            return n + 16
+
+        def process_batch(self, chunks, flags=3, frames_into=None):
+            out = []
+            for i, c in enumerate(chunks):
+                v = frames_into[i][: len(c) + 16]
+                v[:16] = 0x5A
+                v[16:] = c
+                out.append(ChunkResult(frame=v, md5=bytes(16) if flags & 2 else None))
+            return out
+
+        def decompress_batch(self, frames, raw_lens, want_md5=False, into=None):
+            outs = []
+            for f, r, o in zip(frames, raw_lens, into):
+                o[:r] = f[16:16 + r]
+                outs.append(o[:r])
+            return (outs, [bytes(16)] * len(outs)) if want_md5 else outs
+
+        def close(self):
+            pass
+
+    return NullContext()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=256)
@@ -69,10 +107,11 @@ def main():
     ap.add_argument("--connections", type=int, default=8)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--workers", type=int, default=1)
-    ap.add_argument("--context", choices=["hip", "emu"], default="hip")
+    ap.add_argument("--no-prealloc", action="store_true", help="let the operators grow their pinned arenas inside the timed region (round-1 behaviour)")
+    ap.add_argument("--context", choices=["hip", "emu", "null"], default="hip")
     a = ap.parse_args()
     size = a.chunk_kib << 10
-    factory = emu_context_factory if a.context == "emu" else None
+    factory = {"emu": emu_context_factory, "null": null_context_factory}.get(a.context)
     if a.context == "emu":
         from tests.emu import emulib
         emulib.lib()                                    # build before anything forks
@@ -103,6 +142,7 @@ def main():
         port = port_q.get(timeout=120)
         err_ev, err_q = Event(), Queue()
         kw = {"context_factory": factory} if factory else {}
+        kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
                                 max_chunk_bytes=size, device_ids=[0], **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=a.workers,
@@ -113,6 +153,7 @@ def main():
         stop_drain = threading.Event()
         status_records = []
         wire = [0] * K
+        trace = {"compressed": [], "sent": [], "decoded": []}
 
         def collect():
             got = 0
@@ -125,6 +166,7 @@ def main():
                     ready[cr.chunk.chunk_id] = cr
                     ready_cv.notify_all()
                 got += 1
+                trace["compressed"].append(time.perf_counter())
 
         def drain_status():
             while not stop_drain.is_set() or not src.chunk_status_queue.empty() or not dst_store.chunk_status_queue.empty():
@@ -146,11 +188,10 @@ def main():
                         return
                     dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
                     dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
-                    header, payload = hip_sender.wire_payload(src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
-                    header.to_socket(sock)
-                    sock.sendall(payload)
+                    n_sent = hip_sender.send_chunk(sock, src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
                     if idx:
-                        wire[k] += len(payload)
+                        wire[k] += n_sent
+                    trace["sent"].append(time.perf_counter())
 
         def wait_decoded(n):
             got = 0
@@ -158,6 +199,7 @@ def main():
                 try:
                     dq_out.q.get(timeout=0.2)
                     got += 1
+                    trace["decoded"].append(time.perf_counter())
                 except pyqueue.Empty:
                     pass
             return got
@@ -192,14 +234,19 @@ def main():
         rx.join(60)
         assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
         assert n_dec == a.chunks and n_rx == total
-        for cr in warm + main_reqs:
+        for cr in (warm + main_reqs if a.context != "null" else []):
             got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
             assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
         raw = a.chunks * size
+        if os.environ.get("E2E_TRACE"):
+            for name, ts in trace.items():
+                ts = sorted(t - t0 for t in ts if t >= t0)
+                if ts:
+                    print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
-                          "status_records": len(status_records), "verified": True}))
+                          "status_records": len(status_records), "verified": a.context != "null"}))
 
 
 if __name__ == "__main__":

@@ -702,25 +702,44 @@ int skyhip_decompress_batch_md5(skyhip_ctx* c, int n, const uint8_t* const* in, 
         ooff[i] = otot; ocap[i] = out_cap[i]; otot += (out_cap[i] + 255) & ~(uint64_t)255;
     }
     HIPCHK(c, c->dec.d_stage_in.ensure(itot + 256)); HIPCHK(c, c->dec.d_stage_out.ensure(otot + 256));
+    // A pipeline over sub-batches of max_batch frames: every upload is queued on s_up at once (one event per sub-batch), the decoder starts on a
+    // sub-batch when its frames are resident, and the decoded chunks leave on s_down while later sub-batches still upload and decode.  The digests
+    // are one launch at the end: MD5 is a serial chain of ~80 ms per chunk however few chunks a launch holds, so per-sub-batch launches on one
+    // stream would only queue behind each other.
+    const size_t mb = (size_t)c->max_batch, n_sub = ((size_t)n + mb - 1) / mb;
+    while (c->ev_up.size() < n_sub) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_up.push_back(e);
+    }
     int rc = SKYHIP_OK;
     hipError_t he = hipSuccess;
-    for (int i = 0; i < n && he == hipSuccess; i++)
-        if (in_len[i]) he = hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_lz4);
-    if (he == hipSuccess) {
-        rc = sky_lz4d_run(&c->dec, c->s_lz4, n, c->dec.d_stage_in.p, ioff.data(), ilen.data(), c->dec.d_stage_out.p, ooff.data(), ocap.data(), olen.data(),
-                          status, &c->dec_ms, c->hip_err, sizeof c->hip_err);
-        if (rc == SKYHIP_OK || rc == SKYHIP_E_FORMAT) {
-            // frames go home on the download stream while the digests of the decoded bytes are computed where they lie
-            for (int i = 0; i < n && he == hipSuccess; i++) {
-                out_len[i] = (size_t)olen[i];
-                if (olen[i]) he = hipMemcpyAsync(out[i], c->dec.d_stage_out.p + ooff[i], olen[i], hipMemcpyDeviceToHost, c->s_down);
-            }
-            if (md5 && he == hipSuccess) {
-                const int mrc = sky_process_impl(c, n, c->dec.d_stage_out.p, ooff.data(), olen.data(), nullptr, nullptr, nullptr, nullptr, md5, SKYHIP_F_MD5, nullptr);
-                if (mrc != SKYHIP_OK) rc = mrc;
-            }
+    for (size_t sb = 0; sb < n_sub && he == hipSuccess; sb++) {
+        const size_t lo = sb * mb, hi = lo + mb < (size_t)n ? lo + mb : (size_t)n;
+        for (size_t i = lo; i < hi && he == hipSuccess; i++)
+            if (in_len[i]) he = hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_up);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_up[sb], c->s_up);
+    }
+    for (size_t sb = 0; sb < n_sub && he == hipSuccess; sb++) {
+        const size_t lo = sb * mb, hi = lo + mb < (size_t)n ? lo + mb : (size_t)n;
+        he = hipStreamWaitEvent(c->s_lz4, c->ev_up[sb], 0);
+        if (he != hipSuccess) break;
+        const int src = sky_lz4d_run(&c->dec, c->s_lz4, (int)(hi - lo), c->dec.d_stage_in.p, ioff.data() + lo, ilen.data() + lo, c->dec.d_stage_out.p,
+                                     ooff.data() + lo, ocap.data() + lo, olen.data() + lo, status ? status + lo : nullptr, &c->dec_ms, c->hip_err,
+                                     sizeof c->hip_err);
+        if (src != SKYHIP_OK && src != SKYHIP_E_FORMAT) { rc = src; break; }
+        if (src == SKYHIP_E_FORMAT) rc = src;
+        for (size_t i = lo; i < hi && he == hipSuccess; i++) {      // sky_lz4d_run returned: these bytes are final
+            out_len[i] = (size_t)olen[i];
+            if (olen[i]) he = hipMemcpyAsync(out[i], c->dec.d_stage_out.p + ooff[i], olen[i], hipMemcpyDeviceToHost, c->s_down);
         }
     }
+    if (md5 && he == hipSuccess && (rc == SKYHIP_OK || rc == SKYHIP_E_FORMAT)) {
+        const int mrc = sky_process_impl(c, n, c->dec.d_stage_out.p, ooff.data(), olen.data(), nullptr, nullptr, nullptr, nullptr, md5, SKYHIP_F_MD5, nullptr);
+        if (mrc != SKYHIP_OK) rc = mrc;
+    }
+    const hipError_t e0 = hipStreamSynchronize(c->s_up);
+    if (he == hipSuccess) he = e0;
     const hipError_t e1 = hipStreamSynchronize(c->s_lz4), e2 = hipStreamSynchronize(c->s_down);   // the caller's buffers are ours until here
     if (he == hipSuccess) he = e1 != hipSuccess ? e1 : e2;
     if (he != hipSuccess) {

@@ -135,7 +135,8 @@ class GatewayHipCompress(GatewayOperator):
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
-                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004):
+                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004,
+                 prealloc: bool = False):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
         self.max_batch = int(max_batch)
         self.max_chunk_bytes = int(max_chunk_bytes)
@@ -153,6 +154,9 @@ class GatewayHipCompress(GatewayOperator):
         # a lane that finds fewer than max_batch requests waits this long once for more before it launches: trickling input otherwise
         # turns into many one-chunk calls that each pay the full chain latency
         self.fill_wait_s = float(fill_wait_s)
+        # size every lane's pinned arenas for max_batch chunks of max_chunk_bytes when the lane starts, instead of growing them under the first full
+        # batches: pinning fresh host memory runs at a few GB/s, which a transfer of seconds would otherwise pay inside its first batches
+        self.prealloc = bool(prealloc)
         self._tls = threading.local()
 
     # -- process-local ---------------------------------------------------------------------------------
@@ -278,8 +282,23 @@ class GatewayHipCompress(GatewayOperator):
                 break
         return batch
 
+    def _prealloc(self):
+        ctx = self._context()
+        if not (hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound")):
+            return
+        per = (ctx.frame_bound(self.max_chunk_bytes) + 255) & ~255
+        for which in ("in", "out"):
+            self._arena(ctx, which, per * self.max_batch)[::4096] = 0
+
     def _lane_loop(self, worker_id: int):
         """One pipeline lane: drain up to max_batch requests, one device call, hand the chunks on."""
+        if self.prealloc:
+            try:
+                self._prealloc()
+            except Exception:
+                self.error_queue.put(traceback.format_exc())
+                self.error_event.set()
+                self.exit_flags[worker_id].set()
         while not self.exit_flags[worker_id].is_set() and not self.error_event.is_set():
             try:
                 batch = self._take_batch()

@@ -7,6 +7,7 @@ raw_data_len (:204-218), stop when n_chunks_left_on_socket == 0 (:235-237).  End
 socket profiler queue are out of scope.  A size mismatch raises instead of retrying forever."""
 from __future__ import annotations
 
+import mmap
 import os
 import socket
 from typing import Callable, List, Optional
@@ -40,15 +41,17 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
             # deferred decode: stream the payload to its sidecar in recv_block_size pieces, never holding it whole
             final = sidecar.compressed_path(chunk_store, header.chunk_id)
             tmp = final.with_suffix(".rxtmp")
-            buf = bytearray(min(header.data_len, recv_block_size) or 1)
             got = 0
-            with open(tmp, "wb") as f:
-                while got < header.data_len:
-                    n = conn.recv_into(buf, min(header.data_len - got, len(buf)))
-                    if n == 0:
-                        raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
-                    f.write(memoryview(buf)[:n])
-                    got += n
+            with open(tmp, "w+b") as f:
+                if header.data_len:
+                    # the socket's bytes land in the file's pages (one copy: kernel socket buffer -> page cache), not in a bounce buffer first
+                    f.truncate(header.data_len)
+                    with mmap.mmap(f.fileno(), header.data_len) as mm, memoryview(mm) as view:
+                        while got < header.data_len:
+                            n = conn.recv_into(view[got:], min(header.data_len - got, recv_block_size))
+                            if n == 0:
+                                raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
+                            got += n
             os.replace(tmp, final)
             received.append(header.chunk_id)
             if header.n_chunks_left_on_socket == 0:

@@ -5,6 +5,7 @@ replacement for those lines: ship the pre-compressed sidecar when present, other
 the receiver (gateway_receiver.py:142-237) and chunk.py stay untouched.  INTEGRATION.md shows the ~10-line patch."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
@@ -26,15 +27,34 @@ def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left
     return header, data
 
 
+def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int) -> int:
+    """Header + payload of one chunk, the payload straight from its file to the socket (``socket.sendfile`` -> os.sendfile on a plain TCP
+    socket): the same bytes ``wire_payload`` + ``sendall`` put on the wire without the copy through a Python ``bytes`` -- the frame was
+    produced by the GPU, the CPU has no reason to touch it.  Returns the payload bytes sent.  (A TLS-wrapped socket, as the reference uses
+    when e2ee/TLS is on, falls back to read + send inside ``sendfile`` itself.)"""
+    chunk = chunk_req.chunk
+    frame_path = sidecar.compressed_path(chunk_store, chunk.chunk_id)
+    compressed = frame_path.exists()
+    path = frame_path if compressed else chunk_store.get_chunk_file_path(chunk.chunk_id)
+    with open(path, "rb") as f:
+        size = os.fstat(f.fileno()).st_size
+        if not compressed:
+            assert size == chunk.chunk_length_bytes, f"chunk {chunk.chunk_id} has size {size} but should be {chunk.chunk_length_bytes}"
+        header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=size, raw_wire_length=chunk.chunk_length_bytes,
+                                      is_compressed=compressed)
+        header.to_socket(sock)
+        sent = sock.sendfile(f, 0, size) if size else 0
+    if sent != size:
+        raise ConnectionError(f"chunk {chunk.chunk_id}: {sent} of {size} payload bytes sent")
+    return size
+
+
 def send_chunks(sock, chunk_store: ChunkStore, chunk_reqs) -> int:
     """The per-connection send loop of GatewaySender.process (gateway_operator.py:343-402) minus its HTTP
     pre-registration and retry-on-reconnect: header, then payload, for every chunk; returns wire bytes sent."""
     sent = 0
     for idx, chunk_req in enumerate(chunk_reqs):
-        header, payload = wire_payload(chunk_store, chunk_req, n_chunks_left_on_socket=len(chunk_reqs) - idx - 1)
-        header.to_socket(sock)
-        sock.sendall(payload)
-        sent += len(payload)
+        sent += send_chunk(sock, chunk_store, chunk_req, n_chunks_left_on_socket=len(chunk_reqs) - idx - 1)
     return sent
 
 
