@@ -42,8 +42,8 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
     memset(T, 0xFF, (size_t)NB * LZ4S_Q * 4);
     if (n >= 13u) {
         const uint32_t mflimit = n - 12u, matchlimit = n - 5u;
-        // pre-pass: earliest position per (bucket, region) among equal tags
-        for (uint32_t p = 0; p <= mflimit; p++) {
+        // pre-pass: earliest position per (bucket, region) among equal tags; every LZ4S_INS_STEP-th position is entered
+        for (uint32_t p = 0; p <= mflimit; p += LZ4S_INS_STEP) {
             const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
             uint32_t* e = &T[LZ4S_BUCKET(x) * LZ4S_Q + (p >> LZ4S_RLOG)];
             const uint32_t v = LZ4S_ENTRY(LZ4S_TAG(x), p & ((1u << LZ4S_RLOG) - 1u));
@@ -86,8 +86,11 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                         if (t < 8u) break;
                     }
                 }
+                // move the start back over pending literals: at most LZ4S_BACK bytes, 4 when the match is the distance-4 one (the kernel has the
+                // 8 bytes before every table candidate in registers, but only 4 of the 8 before position p - 4)
+                const uint32_t backmax = bc + 4u == p ? 4u : LZ4S_BACK;
                 uint32_t nb = 0;
-                while (nb < LZ4S_BACK && p - nb > lanchor && bc - nb > 0u && s[p - nb - 1u] == s[bc - nb - 1u]) nb++;
+                while (nb < backmax && p - nb > lanchor && bc - nb > 0u && s[p - nb - 1u] == s[bc - nb - 1u]) nb++;
                 const uint32_t mp = p - nb, c0 = bc - nb;
                 len += nb;
                 rec[j * 16u + nrec[j]++] = LZ4S_REC(mp - c0, mp - lanchor, len);

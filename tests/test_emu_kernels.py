@@ -69,6 +69,32 @@ def test_emu_long_matches_and_overlap():
     assert len(frames[0]) < 1200
 
 
+def _emit_corner_cases():
+    """Blocks aimed at the emit step: literal runs around 15 / 64 / 255-multiples (token nibble, extension bytes, the workgroup-wide copy of runs
+    longer than 64), match lengths around 19 / 274 / 1039 (one, two, five extension bytes), runs that start or end a block, neighbours that meet
+    inside an image dword."""
+    rng = np.random.default_rng(7)
+
+    def rnd(n):
+        return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+
+    cases = [rnd(1000) + bytes(60000) + rnd(300) + b"abcdefgh" * 400,
+             rnd(70) + bytes(100) + rnd(200) + bytes(300) + rnd(1100) + b"xy" * 3000 + rnd(5000) + (rnd(37) * 500),
+             b"".join(rnd(int(rng.integers(1, 400))) + bytes(int(rng.integers(4, 2000))) for _ in range(60))[:65536],
+             b"".join(rnd(int(rng.integers(60, 90))) + (b"Q" * int(rng.integers(4, 30))) for _ in range(700))[:65536],
+             (rnd(255 * 3 + 15 + 5) + bytes(19) + rnd(15) + bytes(270 + 4) + rnd(14) + bytes(269 + 4) + rnd(16) + bytes(1020 + 15 + 4 + 3)) * 8]
+    unit = rnd(23) + b"ab" * 40 + rnd(9) + bytes(50)
+    for n in (13, 64, 65, 100, 4095, 4096, 4097, 65535, 65536):
+        cases.append((unit * (n // len(unit) + 1))[:n])
+    return cases + [b"".join(cases)]
+
+
+def test_emu_emit_corner_cases():
+    cases = _emit_corner_cases()
+    frames, md5s, _ = emulib.process(cases)
+    _check(cases, frames, md5s)
+
+
 def test_emu_incompressible_blocks_are_stored_raw():
     d = synth.gen_random(synth.rng_for(0, 2), 3 * 65536 + 100).tobytes()
     frames, md5s, cs = emulib.process([d])

@@ -91,6 +91,15 @@ def test_long_matches_and_overlap(ctx):
     _check(pats, ctx.process_batch(pats))
 
 
+def test_emit_corner_cases(ctx):
+    """Literal runs / match lengths around every extension-byte boundary, runs longer than 64 (copied by the whole workgroup), neighbouring lanes
+    meeting inside an image dword: the same blocks the emulator runs (tests/test_emu_kernels.py)."""
+    from tests.test_emu_kernels import _emit_corner_cases
+
+    cases = _emit_corner_cases()
+    _check(cases, ctx.process_batch(cases))
+
+
 def test_md5_only_and_lz4_only(ctx, small_cases):
     from skyplane_amd import hip_ops
 
