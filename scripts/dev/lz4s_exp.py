@@ -32,6 +32,19 @@ for label, flags in runs:
         ol, _ = ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, flags)
     t = ctx.timing()
     print(f"{label:8s} lz4 {t.lz4_ms/R:8.2f} ms ({n*cb/(max(t.lz4_ms,1e-9)/R/1e3)/1e9:7.1f} GB/s of input)  md5 {t.md5_ms/R:8.2f} ms  gather {t.gather_ms/R:6.2f} ms  ratio {n*cb/max(int(ol.sum()),1):.4f}", flush=True)
+    if os.environ.get("BY_WAVE") and label == "lz4":      # per wave of the workgroup: mean cycles per block in every phase (prof builds)
+        allc = {}
+        for w in range(16):
+            os.environ["SKYHIP_PROF_WAVE"] = str(w)
+            for _ in range(R):
+                ctx.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap, flags)
+            ctx._lib.skyhip_debug_prof(ctx._h, pr)
+            allc[w] = [pr[i] / max(pr[12], 1) for i in range(12)]
+        del os.environ["SKYHIP_PROF_WAVE"]
+        print("  wave:  " + " ".join(f"{w:6d}" for w in range(16)))
+        for i in range(11):
+            print(f"  {names[i][:22]:22s} " + " ".join(f"{allc[w][i]:6.0f}" for w in range(16)))
+        continue
     ctx._lib.skyhip_debug_prof(ctx._h, pr)
     if pr[12] and label == "lz4":
         tot = pr[11]

@@ -790,7 +790,11 @@ int skyhip_debug_prof(skyhip_ctx* c, uint64_t out[16]) {
         uint64_t all[64 * 16];      // 64 copies (see the kernels): summed here
         HIPCHK(c, hipMemcpy(all, c->d_prof, sizeof all, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof all));
-        for (int k = 0; k < 64; k++) for (int i = 0; i < 16; i++) out[i] += all[16 * k + i];
+        // copy k was fed by the waves with (workgroup * 16 + wave) % 64 == k, i.e. by wave k % 16 of its workgroup: SKYHIP_PROF_WAVE=w keeps that wave's
+        // counters only (which waves does a barrier wait for?)
+        const char* e = getenv("SKYHIP_PROF_WAVE");
+        const int only = e ? atoi(e) : -1;
+        for (int k = 0; k < 64; k++) if (only < 0 || (k & 15) == only) for (int i = 0; i < 16; i++) out[i] += all[16 * k + i];
     }
     return SKYHIP_OK;
 }
