@@ -45,10 +45,6 @@ SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) {
 // arbitrary gather across lanes (ds_bpermute_b32)
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 SKY_DEV void sky_syncthreads() { __syncthreads(); }
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of the wave (s_waitcnt vmcnt(0)), i.e.
-// it exposes the full HBM round trip of a store nobody in the workgroup will read.  Use where the barrier protects LDS contents; global results of
-// the kernel become visible at its end as usual.
-SKY_DEV void sky_syncthreads_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // compiler-only: nothing is scheduled across this point (keeps unrolled load groups from being merged and spilled)
 SKY_DEV void sky_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // s_setprio: issue priority of this wave among the waves of its SIMD (0 = default ... 3)
