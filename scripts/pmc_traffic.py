@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only -- see scripts/gpu_r2g.sh) over
+"""Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only -- see scripts/gpu_r2z2.sh) over
 scripts/dev/lz4s_exp.py to bytes per launch of the dominant kernel and per input byte, and write profiles/traffic.json entries.
-FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads
-(MI355X_MICROARCH.md, HBM section): the read side is doubled here and the raw figure kept beside it."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 bytes per
+lane); other access widths and WRITE_SIZE are uncalibrated (MI355X_MICROARCH.md, HBM section).  This kernel's one wide streaming read is the input
+itself -- N bytes, every byte once, global_load_dwordx4 -- so N/2 of it is missing from the counter: fetch = raw + N/2.  The rest of the raw figure
+(4-byte prefetch touches, reloads of spilled registers) is taken at face value.  The raw counter and the figure with EVERY fetch doubled are kept
+beside it."""
 import csv, json, sys
 from pathlib import Path
 out_dir, stream, chunks, kernel = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3]), sys.argv[4]
@@ -12,10 +15,13 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == name]
     res[name] = (sum(vals) / len(vals) * 1024.0, len(vals))        # bytes per launch (mean over the launches seen)
 inp = chunks * 8 * 1024 * 1024
-entry = {"fetch_bytes_per_input_byte": round(2.0 * res["FETCH_SIZE"][0] / inp, 4), "fetch_bytes_per_input_byte_raw_counter": round(res["FETCH_SIZE"][0] / inp, 4),
-         "write_bytes_per_input_byte": round(res["WRITE_SIZE"][0] / inp, 4), "launches_measured": res["FETCH_SIZE"][1], "chunks_per_launch": chunks,
+raw_f, wr = res["FETCH_SIZE"][0] / inp, res["WRITE_SIZE"][0] / inp
+entry = {"fetch_bytes_per_input_byte": round(raw_f + 0.5, 4), "fetch_bytes_per_input_byte_raw_counter": round(raw_f, 4),
+         "fetch_bytes_per_input_byte_all_doubled": round(2.0 * raw_f, 4), "write_bytes_per_input_byte": round(wr, 4),
+         "launches_measured": res["FETCH_SIZE"][1], "chunks_per_launch": chunks,
          "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {kernel}, {chunks} x 8 MiB chunks per launch, stream {stream}; "
-                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-byte requests as 64)"}
+                   "fetch = raw counter + half of the input (gfx950 tallies the 128-byte requests of the coalesced 16-byte-per-lane stream read at 64 bytes, "
+                   "MI355X_MICROARCH.md; other widths -- prefetch touches, spill reloads -- at face value)"}
 tf = Path(__file__).resolve().parents[1] / "profiles" / "traffic.json"
 allv = json.loads(tf.read_text()) if tf.exists() else {}
 if "source" in allv:      # round-1 format (one global entry): superseded
