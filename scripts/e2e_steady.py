@@ -59,7 +59,31 @@ def emu_context_factory(device_id, max_chunk_bytes, max_batch):
         def close(self):
             pass
 
-    return EmuContext()
+    class EmuDedupContext(EmuContext):
+        """+ Gear CDC, fingerprints and the dedup table (--dedup-wire): the call shape of skyhip_cdc_results / skyhip_dedup_reset."""
+
+        def __init__(self):
+            from oracle import ref
+
+            self.cdc, self.gear, self.last = emulib.EmuCdc(16), ref.gear_table(), None
+
+        def process_batch(self, chunks, flags=3, frames_into=None):
+            raw = [bytes(c) for c in chunks]
+            frames, md5s, _ = emulib.process(raw, flags=flags & 3)
+            if flags & 4:
+                prefix, seg_end, fps, first, base, _ = self.cdc.run(raw, self.gear, dedup=bool(flags & 8))
+                self.last = (prefix.astype("uint64"), seg_end, fps, first, base)
+            return [ChunkResult(frame=f if flags & 1 else None, md5=m if flags & 2 else None) for f, m in zip(frames, md5s)]
+
+        def cdc_results(self, n, in_len):
+            return self.last
+
+        def dedup_reset(self):
+            base = self.cdc.seg_base
+            self.cdc = emulib.EmuCdc(16)
+            self.cdc.seg_base = base
+
+    return EmuDedupContext() if os.environ.get("E2E_DEDUP_WIRE") else EmuContext()
 
 
 def null_context_factory(device_id, max_chunk_bytes, max_batch):
@@ -109,7 +133,11 @@ def main():
     ap.add_argument("--workers", type=int, default=1)
     ap.add_argument("--no-prealloc", action="store_true", help="let the operators grow their pinned arenas inside the timed region (round-1 behaviour)")
     ap.add_argument("--context", choices=["hip", "emu", "null"], default="hip")
+    ap.add_argument("--dedup-wire", action="store_true", help="dedup on the wire (gateway/dedup_wire.py): a 50 %%-duplicate stream, recipes instead of frames, "
+                                                            "one destination worker process (its lanes share the segment store)")
     a = ap.parse_args()
+    if a.dedup_wire:
+        os.environ["E2E_DEDUP_WIRE"] = "1"
     size = a.chunk_kib << 10
     factory = {"emu": emu_context_factory, "null": null_context_factory}.get(a.context)
     if a.context == "emu":
@@ -124,11 +152,12 @@ def main():
         dq_in, dq_out = GatewayQueue(), GatewayQueue()
         dst_store.add_partition("0", dq_in)
         base = synth.mixed_chunks(4, size, config_id=4)
+        dd_stream = synth.dedup_stream((a.connections + a.chunks) * size, dup_fraction=0.5, config_id=3) if a.dedup_wire else None
         digests = {}
 
         def make(i):
             cid = uuid.uuid4().hex
-            data = base[i % 4].tobytes()
+            data = base[i % 4].tobytes() if dd_stream is None else dd_stream[i * size:(i + 1) * size].tobytes()
             src.get_chunk_file_path(cid).write_bytes(data)
             digests[cid] = hashlib.md5(data).digest()
             return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
@@ -144,8 +173,8 @@ def main():
         kw = {"context_factory": factory} if factory else {}
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
-                                max_chunk_bytes=size, device_ids=[0], **kw)
-        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=a.workers,
+                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, **kw)
+        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if a.dedup_wire else a.workers,
                                    max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
@@ -244,7 +273,7 @@ def main():
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "dedup_wire": a.dedup_wire, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null"}))
 

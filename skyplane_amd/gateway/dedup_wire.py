@@ -1,0 +1,136 @@
+"""Dedup on the wire: the payload sub-format that lets the GPU's CDC / fingerprint / dedup-table results save egress bytes.
+
+Not in the reference (it has no chunking or dedup of any kind); the wire HEADER (skyplane/chunk.py:95-167) is untouched.  With
+``dedup_wire`` configured on both gateways -- the planner writes both programs -- the source operator ships, in the place of
+the chunk's LZ4 frame and still flagged ``is_compressed``, a *recipe*:
+
+    magic "SKYD" | version u8 | lane u64 | epoch u32 | nseg u32 | raw_len u32 | lit_raw_len u32 | lit_frame_len u32        (33 bytes)
+    nseg x { seg_len u32 | kind u8 (0 literal, 1 reference) | fingerprint 16 bytes }                                        (21 bytes each)
+    one LZ4 frame of the chunk's literal segments, concatenated in order                                                   (lit_frame_len bytes)
+
+A payload that starts with the LZ4 frame magic (04 22 4D 18) is a plain frame as before, so the two cannot be confused.  Segments are the Gear-CDC
+segments of the chunk (skyplane_amd/csrc/gear_kernel.inc; 1 / 4 / 16 KiB), fingerprints their MD5.  A *reference* names a segment with the same
+fingerprint that the same source lane sent as a literal earlier in the same epoch: ``lane`` is a random id of one source pipeline lane (= one device
+dedup table), ``epoch`` counts that table's resets.  The destination keeps the literal segments of the current and the previous epoch of every lane
+(``SegmentStore``) and rebuilds the chunk; a reference whose literal has not arrived yet (chunks travel on different connections) makes the chunk
+"not ready" -- it is re-queued like a payload that has not arrived -- and the whole-chunk MD5 that already travels beside the chunk is the final check.
+Every chunk of a deduplicating lane goes out as a recipe, also one without duplicates (its literal frame is then the frame the compressor produced
+anyway): the destination can only resolve references to segments it has been told about."""
+from __future__ import annotations
+
+import struct
+import threading
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+MAGIC = b"SKYD"
+VERSION = 1
+LZ4F_MAGIC = b"\x04\x22\x4d\x18"
+_HDR = struct.Struct("<4sBQIIIII")
+HEADER_BYTES = _HDR.size           # 33
+SEG_DTYPE = np.dtype([("len", "<u4"), ("kind", "u1"), ("fp", "u1", (16,))])
+SEG_BYTES = SEG_DTYPE.itemsize     # 21
+KIND_LITERAL, KIND_REFERENCE = 0, 1
+
+
+class RecipeError(ValueError):
+    """A payload that claims to be a recipe and is not well formed."""
+
+
+@dataclass
+class Recipe:
+    lane: int
+    epoch: int
+    raw_len: int
+    lit_raw_len: int
+    segs: np.ndarray                 # SEG_DTYPE[nseg]
+    lit_frame: memoryview            # the LZ4 frame of the literal bytes (a view of the payload)
+
+
+def is_recipe(payload) -> bool:
+    return bytes(payload[:4]) == MAGIC
+
+
+def encode_recipe(lane: int, epoch: int, seg_lens, kinds, fps, lit_frame, lit_raw_len: int) -> bytes:
+    """seg_lens: nseg lengths; kinds: nseg 0/1; fps: [nseg, 16] uint8; lit_frame: bytes-like LZ4 frame of the literal bytes."""
+    seg_lens = np.asarray(seg_lens, np.uint32)
+    kinds = np.asarray(kinds, np.uint8)
+    fps = np.asarray(fps, np.uint8).reshape(-1, 16)
+    n = seg_lens.size
+    assert kinds.size == n and fps.shape[0] == n
+    assert int(seg_lens[kinds == KIND_LITERAL].sum()) == int(lit_raw_len)
+    segs = np.zeros(n, SEG_DTYPE)
+    segs["len"], segs["kind"], segs["fp"] = seg_lens, kinds, fps
+    lit = bytes(lit_frame)
+    return _HDR.pack(MAGIC, VERSION, lane & 0xFFFFFFFFFFFFFFFF, epoch, n, int(seg_lens.sum()), int(lit_raw_len), len(lit)) + segs.tobytes() + lit
+
+
+def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
+    """Every length is checked against the payload before anything is sliced; raises RecipeError."""
+    mv = memoryview(payload).cast("B") if not isinstance(payload, memoryview) else payload
+    if len(mv) < HEADER_BYTES:
+        raise RecipeError(f"recipe of {len(mv)} bytes is shorter than its header")
+    magic, ver, lane, epoch, nseg, raw_len, lit_raw, lit_frame_len = _HDR.unpack_from(mv, 0)
+    if magic != MAGIC or ver != VERSION:
+        raise RecipeError(f"not a recipe (magic {bytes(magic)!r}, version {ver})")
+    if max_raw_len is not None and raw_len > max_raw_len:
+        raise RecipeError(f"recipe for {raw_len} bytes, limit {max_raw_len}")
+    if HEADER_BYTES + SEG_BYTES * nseg + lit_frame_len != len(mv):
+        raise RecipeError(f"recipe lengths do not add up: header + {nseg} segments + {lit_frame_len} != {len(mv)}")
+    segs = np.frombuffer(mv, SEG_DTYPE, count=nseg, offset=HEADER_BYTES)
+    if nseg and int(segs["kind"].max()) > KIND_REFERENCE:
+        raise RecipeError("unknown segment kind")
+    if int(segs["len"].astype(np.uint64).sum()) != raw_len:
+        raise RecipeError("segment lengths do not add up to the chunk length")
+    if int(segs["len"][segs["kind"] == KIND_LITERAL].astype(np.uint64).sum()) != lit_raw:
+        raise RecipeError("literal segment lengths do not add up to the literal stream's length")
+    if lit_raw and not lit_frame_len:
+        raise RecipeError("literal bytes announced but no literal frame")
+    return Recipe(lane=lane, epoch=epoch, raw_len=raw_len, lit_raw_len=lit_raw, segs=segs, lit_frame=mv[HEADER_BYTES + SEG_BYTES * nseg:])
+
+
+class SegmentStore:
+    """Literal segments by (lane, epoch, fingerprint), shared by the lanes (threads) of one destination worker process.  A lane's table is reset at
+    every epoch change, so a reference of epoch e can only name a literal of epoch e; chunks of epoch e - 1 may still be in flight when e begins, so
+    the last ``keep_epochs`` epochs of a lane are kept and older ones dropped when a newer one shows up."""
+
+    def __init__(self, keep_epochs: int = 2):
+        self.keep_epochs = max(1, int(keep_epochs))
+        self._lock = threading.Lock()
+        self._segs: Dict[Tuple[int, int], Dict[bytes, bytes]] = {}
+        self.bytes_held = 0
+
+    def _retire(self, lane: int, epoch: int):
+        for key in [k for k in self._segs if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
+            self.bytes_held -= sum(len(v) for v in self._segs.pop(key).values())
+
+    def put_many(self, lane: int, epoch: int, fps: List[bytes], datas: List[bytes]):
+        with self._lock:
+            self._retire(lane, epoch)
+            d = self._segs.setdefault((lane, epoch), {})
+            for fp, data in zip(fps, datas):
+                if fp not in d:
+                    d[fp] = data
+                    self.bytes_held += len(data)
+
+    def get(self, lane: int, epoch: int, fp: bytes) -> Optional[bytes]:
+        with self._lock:
+            return self._segs.get((lane, epoch), {}).get(fp)
+
+    def epochs_held(self, lane: int) -> List[int]:
+        with self._lock:
+            return sorted(k[1] for k in self._segs if k[0] == lane)
+
+
+def classify_segments(prefix, cuts, first, base: int, i: int):
+    """Segments of chunk i of a device call, from skyhip_cdc_results: (seg_lens, kinds, slice into the call's fingerprint array).
+    prefix[i]..prefix[i+1] are the chunk's segments in the call's arrays, cuts their END offsets inside the chunk, first[k] the global index of the
+    first segment with that fingerprint since the table was last emptied (== base + k for a segment that is new)."""
+    lo, hi = int(prefix[i]), int(prefix[i + 1])
+    ends = np.asarray(cuts[lo:hi], np.int64)
+    lens = np.diff(np.concatenate([[0], ends])).astype(np.uint32)
+    own = np.arange(base + lo, base + hi, dtype=np.uint64)
+    kinds = (np.asarray(first[lo:hi], np.uint64) < own).astype(np.uint8)
+    return lens, kinds, slice(lo, hi)

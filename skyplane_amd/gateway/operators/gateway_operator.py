@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import os
 import queue
+import random
 import threading
 import time
 import traceback
@@ -28,8 +29,10 @@ from abc import ABC, abstractmethod
 from multiprocessing import Event, Process, Queue
 from typing import Callable, List, Optional
 
+import numpy as np
+
 from skyplane_amd.chunk import ChunkRequest, ChunkState
-from skyplane_amd.gateway import sidecar
+from skyplane_amd.gateway import dedup_wire, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
 
@@ -136,8 +139,14 @@ class GatewayHipCompress(GatewayOperator):
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004,
-                 prealloc: bool = False):
+                 prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 8 << 30):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
+        # dedup on the wire (skyplane_amd/gateway/dedup_wire.py): every chunk leaves as a recipe -- literal segments, LZ4-compressed, plus references to
+        # segments this lane sent before -- instead of as one LZ4 frame.  Needs gpu_decompress(dedup_wire=True) on the destination gateway.
+        self.dedup_wire = bool(dedup_wire)
+        self.dedup_epoch_bytes = int(dedup_epoch_bytes)      # a lane empties its device table (and starts a new epoch) after this many chunk bytes
+        if self.dedup_wire:
+            cdc = dedup = True
         self.max_batch = int(max_batch)
         self.max_chunk_bytes = int(max_chunk_bytes)
         self.device_ids = list(device_ids) if device_ids is not None else list(range(visible_gpu_count()))
@@ -249,14 +258,18 @@ class GatewayHipCompress(GatewayOperator):
             results = ctx.process_batch(datas, flags=self._flags(), frames_into=views)
         else:
             results = ctx.process_batch(datas, flags=self._flags())
+        recipes = self._build_recipes(ctx, datas, results) if self.dedup_wire else None
         self._last_metadata = []
-        for cr, data, res in zip(chunk_reqs, datas, results):
+        for k, (cr, data, res) in enumerate(zip(chunk_reqs, datas, results)):
             cid = cr.chunk.chunk_id
+            payload = recipes[k][0] if recipes is not None else res.frame
             tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
             with open(tmp, "wb") as f:
-                f.write(res.frame)
+                f.write(payload)
             os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
-            meta = {"compressed_size_bytes": len(res.frame), "uncompressed_size_bytes": len(data)}
+            meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": len(data)}
+            if recipes is not None:
+                meta["dedup_reference_bytes"] = recipes[k][1]
             if res.md5 is not None:
                 sidecar.digest_path(self.chunk_store, cid).write_text(res.md5.hex())
                 meta["md5_hex"] = res.md5.hex()
@@ -264,6 +277,37 @@ class GatewayHipCompress(GatewayOperator):
                 meta["cdc_segments"] = int(len(res.cuts))
             self._last_metadata.append(meta)
         return [True] * len(chunk_reqs)
+
+    def _build_recipes(self, ctx, datas, results):
+        """One (payload, referenced bytes) per chunk of the device call that just returned (its CDC results are still the context's last ones)."""
+        st = self._tls.__dict__.setdefault("dedup_state", {"lane": random.getrandbits(64), "epoch": 0, "bytes": 0})
+        in_len = np.array([len(d) for d in datas], np.uint64)
+        prefix, cuts, fps, first, base = ctx.cdc_results(len(datas), in_len)
+        plans, lit_bufs, lit_owner = [], [], []
+        for i, (data, res) in enumerate(zip(datas, results)):
+            lens, kinds, sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
+            if not kinds.any():                        # nothing to leave out: the frame the compressor made IS the literal stream
+                plans.append([lens, kinds, fps[sl], res.frame, len(data)])
+                continue
+            arr = data if isinstance(data, np.ndarray) else np.frombuffer(data, np.uint8)
+            ends = np.cumsum(lens.astype(np.int64))
+            parts = [arr[e - l:e] for e, l, kd in zip(ends, lens, kinds) if kd == dedup_wire.KIND_LITERAL]
+            lit = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+            plans.append([lens, kinds, fps[sl], b"", int(lit.size)])
+            if lit.size:
+                lit_bufs.append(lit)
+                lit_owner.append(i)
+        if lit_bufs:      # second device call, LZ4 only: the fingerprint table is not touched
+            for i, r in zip(lit_owner, ctx.process_batch(lit_bufs, flags=1)):
+                plans[i][3] = r.frame
+        out = [(dedup_wire.encode_recipe(st["lane"], st["epoch"], lens, kinds, fp, frame, nlit), int(lens[kinds == dedup_wire.KIND_REFERENCE].sum()))
+               for lens, kinds, fp, frame, nlit in plans]
+        st["bytes"] += int(in_len.sum())
+        if st["bytes"] >= self.dedup_epoch_bytes:      # bound what the destination has to remember: new epoch, empty table
+            ctx.dedup_reset()
+            st["epoch"] += 1
+            st["bytes"] = 0
+        return out
 
     def process(self, chunk_req: ChunkRequest, **args):
         return self.process_batch([chunk_req])[0]
@@ -363,9 +407,22 @@ class GatewayHipDecompress(GatewayHipCompress):
     GatewayHipCompress; there is no CPU fallback.
     """
 
-    def __init__(self, *args, verify_md5: bool = True, **kwargs):
+    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, **kwargs):
         super().__init__(*args, **kwargs)
         self.verify_md5 = verify_md5
+        # dedup on the wire (dedup_wire.py): payloads that are recipes are rebuilt from their literal stream and the segments earlier chunks
+        # brought.  The segment store is shared by the lanes (threads) of ONE worker process: run this operator with n_processes=1 when the
+        # source deduplicates.  A chunk whose references cannot be resolved yet is re-queued; after dedup_wait_s it is an error.
+        self.dedup_wait_s = float(dedup_wait_s)
+        self._store = None                     # created in the worker process, on the first recipe
+        self._store_lock = threading.Lock()
+        self._first_miss = {}
+
+    def _segment_store(self) -> "dedup_wire.SegmentStore":
+        with self._store_lock:
+            if self._store is None:
+                self._store = dedup_wire.SegmentStore()
+            return self._store
 
     @staticmethod
     def _expected_digest(chunk_req: ChunkRequest) -> Optional[bytes]:
@@ -375,6 +432,39 @@ class GatewayHipDecompress(GatewayHipCompress):
         if isinstance(h, str):
             return bytes.fromhex(h)
         return bytes(h)
+
+    def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit) -> Optional[np.ndarray]:
+        """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream."""
+        store = self._segment_store()
+        segs = rec.segs
+        lens = segs["len"].astype(np.int64)
+        is_lit = segs["kind"] == dedup_wire.KIND_LITERAL
+        lit = lit if isinstance(lit, np.ndarray) else np.frombuffer(lit, np.uint8)
+        lit_ends = np.cumsum(np.where(is_lit, lens, 0))
+        fps = [f.tobytes() for f in segs["fp"]]
+        # this chunk's literals first: they may be what its own (or another waiting chunk's) references name
+        idx = np.nonzero(is_lit)[0]
+        store.put_many(rec.lane, rec.epoch, [fps[k] for k in idx], [lit[lit_ends[k] - lens[k]:lit_ends[k]].tobytes() for k in idx])
+        out = np.empty(rec.raw_len, np.uint8)
+        pos = 0
+        for k in range(len(segs)):
+            n = int(lens[k])
+            if is_lit[k]:
+                out[pos:pos + n] = lit[lit_ends[k] - n:lit_ends[k]]
+            else:
+                seg = store.get(rec.lane, rec.epoch, fps[k])
+                if seg is None:
+                    t0 = self._first_miss.setdefault(cid, time.monotonic())
+                    if time.monotonic() - t0 > self.dedup_wait_s:
+                        raise ValueError(f"[Gateway] chunk {cid}: segment {fps[k].hex()} of lane {rec.lane:#x} epoch {rec.epoch} did not arrive within "
+                                         f"{self.dedup_wait_s:.0f} s (is gpu_decompress running with more than one worker process?)")
+                    return None
+                if len(seg) != n:
+                    raise ValueError(f"[Gateway] chunk {cid}: referenced segment {fps[k].hex()} has {len(seg)} bytes, the recipe says {n}")
+                out[pos:pos + n] = np.frombuffer(seg, np.uint8)
+            pos += n
+        self._first_miss.pop(cid, None)
+        return out
 
     def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
         ctx = self._context()
@@ -398,13 +488,13 @@ class GatewayHipDecompress(GatewayHipCompress):
         pinned = hasattr(ctx, "pinned_buffer")
         paths = [sidecar.compressed_path(self.chunk_store, chunk_reqs[i].chunk.chunk_id) for i in todo]
         sizes = [p.stat().st_size for p in paths]
-        raw_lens = [int(chunk_reqs[i].chunk.chunk_length_bytes) for i in todo]
-        frames, into = [], None
+        chunk_lens = [int(chunk_reqs[i].chunk.chunk_length_bytes) for i in todo]
+        payloads, into = [], None
         if pinned:
             arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
-            out = self._arena(ctx, "out", sum((r + 255) & ~255 for r in raw_lens))
+            out = self._arena(ctx, "out", sum((max(r, 1) + 255) & ~255 for r in chunk_lens))
             into, pi, po = [], 0, 0
-            for p, s, r in zip(paths, sizes, raw_lens):
+            for p, s, r in zip(paths, sizes, chunk_lens):
                 v = arena[pi:pi + s]
                 with open(p, "rb") as f:
                     got, mv = 0, memoryview(v)
@@ -414,19 +504,53 @@ class GatewayHipDecompress(GatewayHipCompress):
                             break
                         got += k
                 assert got == s, f"payload {p.name} shrank while being read"
-                frames.append(v)
+                payloads.append(v)
                 into.append(out[po:po + max(r, 1)])
                 pi += (s + 255) & ~255
                 po += (max(r, 1) + 255) & ~255
         else:
-            frames = [p.read_bytes() for p in paths]
+            payloads = [p.read_bytes() for p in paths]
+        # a payload is an LZ4 frame of the chunk, or a recipe whose literal stream is one (dedup_wire.py): one batched decode for both kinds
+        recipes = [None] * len(todo)
+        frames, raw_lens = list(payloads), list(chunk_lens)
+        for j, (pl, r) in enumerate(zip(payloads, chunk_lens)):
+            if dedup_wire.is_recipe(pl):
+                rec = dedup_wire.parse_recipe(memoryview(pl), max_raw_len=r)
+                if rec.raw_len != r:
+                    raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: recipe for {rec.raw_len} bytes, expected {r}")
+                recipes[j] = rec
+                frames[j], raw_lens[j] = rec.lit_frame, rec.lit_raw_len
+        dec = [j for j in range(len(todo)) if recipes[j] is None or recipes[j].lit_raw_len]       # (a recipe of references only has nothing to decode)
         want = self.verify_md5 and any(self._expected_digest(chunk_reqs[i]) is not None for i in todo)
         kwargs = {"want_md5": True} if want else {}
         if into is not None:
-            kwargs["into"] = into
-        res = ctx.decompress_batch(frames, raw_lens, **kwargs)
-        datas, digests = res if want else (res, [None] * len(todo))
-        for i, p, data, dig, size in zip(todo, paths, datas, digests, sizes):
+            kwargs["into"] = [into[j] for j in dec]
+        datas, digests = [np.zeros(0, np.uint8)] * len(todo), [None] * len(todo)
+        if dec:
+            res = ctx.decompress_batch([frames[j] for j in dec], [raw_lens[j] for j in dec], **kwargs)
+            dd, gg = res if want else (res, [None] * len(dec))
+            for j, d, g in zip(dec, dd, gg):
+                datas[j], digests[j] = d, g
+        # recipes: rebuild; their digests are those of the rebuilt chunks (one more device call, MD5 only)
+        ready = [True] * len(todo)
+        rebuilt = []
+        for j, rec in enumerate(recipes):
+            if rec is None:
+                continue
+            if len(datas[j]) != rec.lit_raw_len:
+                raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {len(datas[j])} bytes, the recipe says {rec.lit_raw_len}")
+            chunk = self._rebuild(chunk_reqs[todo[j]].chunk.chunk_id, rec, datas[j])
+            if chunk is None:
+                ready[j] = False
+                continue
+            datas[j], digests[j] = chunk, None
+            rebuilt.append(j)
+        if want and rebuilt:
+            for j, r in zip(rebuilt, ctx.process_batch([datas[j] for j in rebuilt], flags=2)):
+                digests[j] = r.md5
+        for j, (i, p, data, dig, size) in enumerate(zip(todo, paths, datas, digests, sizes)):
+            if not ready[j]:
+                continue                               # re-queued by the worker loop; its literals are already in the store
             cr = chunk_reqs[i]
             cid = cr.chunk.chunk_id
             if len(data) != cr.chunk.chunk_length_bytes:
@@ -443,6 +567,8 @@ class GatewayHipDecompress(GatewayHipCompress):
             meta = {"compressed_size_bytes": size, "uncompressed_size_bytes": len(data)}
             if dig is not None:
                 meta["md5_hex"] = dig.hex()
+            if recipes[j] is not None:
+                meta["dedup_reference_bytes"] = int(recipes[j].raw_len - recipes[j].lit_raw_len)
             self._last_metadata[i] = meta
             oks[i] = True
         return oks

@@ -165,28 +165,41 @@ def f3():
 # f4
 # ---------------------------------------------------------------------------------------------------------------------
 CONFIG_EDIT = [
-    ('    use_compression: bool = True\n', '    use_compression: bool = True\n    use_gpu_compression: bool = False  # LZ4 + MD5 on the gateway\'s GPU (gpu_compress operator) instead of in GatewaySender\n'),
+    ('    use_compression: bool = True\n', '    use_compression: bool = True\n    use_gpu_compression: bool = False  # LZ4 + MD5 on the gateway\'s GPU (gpu_compress operator) instead of in GatewaySender\n'
+     '    use_gpu_dedup: bool = False  # with use_gpu_compression: content-defined segments the destination already holds are not sent again (INTEGRATION.md section 10)\n'),
 ]
 PROGRAM_EDIT = [           # INTEGRATION.md section 9b (same node as section 4)
     ('class GatewayReceive(GatewayOperator):\n',
      'class GatewayGpuCompress(GatewayOperator):\n'
-     '    def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False):\n'
+     '    def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,\n'
+     '                 dedup_wire: bool = False, dedup_epoch_mb: int = 8192):\n'
      '        super().__init__("gpu_compress")\n'
      '        self.num_workers, self.max_batch, self.max_chunk_mb = num_workers, max_batch, max_chunk_mb\n'
-     '        self.compute_md5, self.cdc, self.dedup = compute_md5, cdc, dedup\n\n\n'
+     '        self.compute_md5, self.cdc, self.dedup = compute_md5, cdc or dedup_wire, dedup or dedup_wire\n'
+     '        self.dedup_wire, self.dedup_epoch_mb = dedup_wire, dedup_epoch_mb\n\n\n'
+     'class GatewayGpuDecompress(GatewayOperator):\n'
+     '    def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False):\n'
+     '        super().__init__("gpu_decompress")\n'
+     '        self.num_workers = 1 if dedup_wire else num_workers      # the segment store lives in one worker process\n'
+     '        self.max_batch, self.max_chunk_mb, self.verify_md5, self.dedup_wire = max_batch, max_chunk_mb, verify_md5, dedup_wire\n\n\n'
      'class GatewayReceive(GatewayOperator):\n'),
 ]
 PLANNER_EDIT = [           # INTEGRATION.md section 9c -- MulticastDirectPlanner.plan
-    ('    GatewaySend,\n)\n', '    GatewaySend,\n    GatewayGpuCompress,\n)\n'),
+    ('    GatewaySend,\n)\n', '    GatewaySend,\n    GatewayGpuCompress,\n    GatewayGpuDecompress,\n)\n'),
     ('            # send to all destination\n            mux_and = src_program.add_operator(GatewayMuxAnd(), parent_handle=obj_store_read, partition_id=partition_id)\n',
      '            # send to all destination\n'
      '            gpu = self.transfer_config.use_compression and getattr(self.transfer_config, "use_gpu_compression", False)\n'
      '            stage = obj_store_read\n'
-     '            if gpu:   # compress + hash on the GPU, once, in front of the fan-out (every destination gets the same frame)\n'
-     '                stage = src_program.add_operator(GatewayGpuCompress(), parent_handle=obj_store_read, partition_id=partition_id)\n'
+     '            dedup = gpu and getattr(self.transfer_config, "use_gpu_dedup", False)\n'
+     '            if gpu:   # compress + hash on the GPU, once, in front of the fan-out (every destination gets the same payload)\n'
+     '                stage = src_program.add_operator(GatewayGpuCompress(dedup_wire=dedup), parent_handle=obj_store_read, partition_id=partition_id)\n'
      '            mux_and = src_program.add_operator(GatewayMuxAnd(), parent_handle=stage, partition_id=partition_id)\n'),
     ('                            compress=self.transfer_config.use_compression,\n                            encrypt=self.transfer_config.use_e2ee,\n                        ),\n                        parent_handle=mux_or,\n',
      '                            compress=self.transfer_config.use_compression and not gpu,\n                            encrypt=self.transfer_config.use_e2ee,\n                        ),\n                        parent_handle=mux_or,\n'),
+    ('                    GatewayReceive(decompress=self.transfer_config.use_compression, decrypt=self.transfer_config.use_e2ee),\n',
+     '                    # recipes are rebuilt by the operator that holds the segment store; the receiver then leaves payloads as they arrive (section 6b)\n'
+     '                    GatewayGpuDecompress(dedup_wire=True) if dedup else\n'
+     '                    GatewayReceive(decompress=self.transfer_config.use_compression, decrypt=self.transfer_config.use_e2ee),\n'),
 ]
 
 
@@ -259,6 +272,18 @@ def f4():
     dst_gw = plan.get_region_gateways("test:dst")[0]
     dprog = json.loads(plan.get_gateway_program_json(dst_gw.gateway_id))
     assert dprog[0]["value"][0]["op_type"] == "receive" and dprog[0]["value"][0]["decompress"] is True      # frames are decoded on arrival as before
+    # use_gpu_dedup: recipes instead of frames -- gpu_compress(dedup_wire) at the source, gpu_decompress(dedup_wire) in the
+    # place of `receive` at the destination, and no effect without use_gpu_compression
+    prog_dd, plan_dd = plan_for(cfg.TransferConfig(use_gpu_compression=True, use_gpu_dedup=True, use_e2ee=False))
+    ops_dd = chain(prog_dd)
+    assert [o["op_type"] for o in ops_dd] == ["read_object_store", "gpu_compress", "mux_and", "mux_or", "send"]
+    assert ops_dd[1]["dedup_wire"] is True and ops_dd[1]["cdc"] is True and ops_dd[1]["dedup"] is True and ops_dd[-1]["compress"] is False
+    ddst = json.loads(plan_dd.get_gateway_program_json(plan_dd.get_region_gateways("test:dst")[0].gateway_id))
+    assert ddst[0]["value"][0]["op_type"] == "gpu_decompress" and ddst[0]["value"][0]["dedup_wire"] is True and ddst[0]["value"][0]["num_workers"] == 1
+    assert ddst[0]["value"][0]["children"][0]["op_type"] == "write_object_store"
+    assert ops[1]["dedup_wire"] is False
+    prog_nd, _ = plan_for(cfg.TransferConfig(use_gpu_dedup=True, use_e2ee=False))
+    assert "gpu_compress" not in json.dumps(prog_nd) and "gpu_decompress" not in json.dumps(prog_nd)
     prog_cpu, _ = plan_for(cfg.TransferConfig(use_e2ee=False))
     ops = chain(prog_cpu)
     assert [o["op_type"] for o in ops] == ["read_object_store", "mux_and", "mux_or", "send"] and ops[-1]["compress"] is True   # default unchanged

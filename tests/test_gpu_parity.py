@@ -339,3 +339,30 @@ def test_error_paths_leave_the_context_usable(ctx):
     assert failed >= 10, failed
     _check([d, b"", d[:70_001]], ctx.process_batch([d, b"", d[:70_001]]))
     assert ctx.decompress_batch([ref.lz4f_compress(d)], [len(d)]) == [d]
+
+
+def test_dedup_wire_operators_roundtrip_on_gpu(ctx, tmp_path):
+    """Dedup on the wire with the real library behind both operators (tests/test_dedup_wire.py runs the same scenario on the emulator): recipes out
+    of skyhip_cdc_results, literal streams compressed by a second LZ4-only call, rebuilt and digest-checked on the destination, fewer bytes than frames."""
+    from skyplane_amd.gateway import dedup_wire, sidecar
+    from tests import test_dedup_wire as T
+
+    chunks = T._dup_chunks(n=8, size=1 << 20)
+    src, dst, reqs = T._stores(tmp_path, chunks)
+    ctx.dedup_reset()
+    comp, dec = T._ops(src, dst, ctx, ctx)
+    comp.max_batch = dec.max_batch = 4                     # the fixture's context
+    for k in (0, 4):
+        assert all(comp.process_batch(reqs[k:k + 4]))
+    payloads = [sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes() for cr in reqs]
+    assert all(dedup_wire.is_recipe(p) for p in payloads)
+    plain = sum(len(r.frame) for k in (0, 4) for r in ctx.process_batch(chunks[k:k + 4], flags=1))
+    assert sum(map(len, payloads)) < 0.8 * plain, (sum(map(len, payloads)), plain)
+    T._ship(src, dst, reqs)
+    oks = dec.process_batch(reqs[4:])                      # the later half first: references into the first half must wait
+    assert all(dec.process_batch(reqs[:4]))
+    waiting = [cr for cr, ok in zip(reqs[4:], oks) if not ok]
+    assert all(dec.process_batch(waiting)) if waiting else True
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+
