@@ -94,30 +94,50 @@ def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
 class SegmentStore:
     """Literal segments by (lane, epoch, fingerprint), shared by the lanes (threads) of one destination worker process.  A lane's table is reset at
     every epoch change, so a reference of epoch e can only name a literal of epoch e; chunks of epoch e - 1 may still be in flight when e begins, so
-    the last ``keep_epochs`` epochs of a lane are kept and older ones dropped when a newer one shows up."""
+    the last ``keep_epochs`` epochs of a lane are kept and older ones dropped when a newer one shows up.  A chunk's literal stream is kept as ONE
+    bytes object and every segment as (that object, offset, length): no per-segment copies, and neighbouring segments stay neighbours, so a run of
+    references into one earlier chunk is rebuilt with one copy."""
 
     def __init__(self, keep_epochs: int = 2):
         self.keep_epochs = max(1, int(keep_epochs))
         self._lock = threading.Lock()
-        self._segs: Dict[Tuple[int, int], Dict[bytes, bytes]] = {}
-        self.bytes_held = 0
+        self._segs: Dict[Tuple[int, int], Dict[bytes, Tuple[bytes, int, int]]] = {}
+        self._bytes: Dict[Tuple[int, int], int] = {}
+
+    @property
+    def bytes_held(self) -> int:
+        with self._lock:
+            return sum(self._bytes.values())
 
     def _retire(self, lane: int, epoch: int):
         for key in [k for k in self._segs if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
-            self.bytes_held -= sum(len(v) for v in self._segs.pop(key).values())
+            del self._segs[key]
+            del self._bytes[key]
 
-    def put_many(self, lane: int, epoch: int, fps: List[bytes], datas: List[bytes]):
+    def put_chunk(self, lane: int, epoch: int, fps: List[bytes], offs, lens, litbuf: bytes):
+        """The literal segments of one chunk: fingerprint k is litbuf[offs[k] : offs[k] + lens[k]]."""
         with self._lock:
             self._retire(lane, epoch)
             d = self._segs.setdefault((lane, epoch), {})
-            for fp, data in zip(fps, datas):
+            new = 0
+            for fp, o, n in zip(fps, offs, lens):
                 if fp not in d:
-                    d[fp] = data
-                    self.bytes_held += len(data)
+                    d[fp] = (litbuf, int(o), int(n))
+                    new += int(n)
+            self._bytes[(lane, epoch)] = self._bytes.get((lane, epoch), 0) + new
+
+    def put_many(self, lane: int, epoch: int, fps: List[bytes], datas: List[bytes]):
+        for fp, data in zip(fps, datas):
+            self.put_chunk(lane, epoch, [fp], [0], [len(data)], bytes(data))
+
+    def get_many(self, lane: int, epoch: int, fps: List[bytes]) -> List[Optional[Tuple[bytes, int, int]]]:
+        with self._lock:
+            d = self._segs.get((lane, epoch), {})
+            return [d.get(fp) for fp in fps]
 
     def get(self, lane: int, epoch: int, fp: bytes) -> Optional[bytes]:
-        with self._lock:
-            return self._segs.get((lane, epoch), {}).get(fp)
+        (hit,) = self.get_many(lane, epoch, [fp])
+        return None if hit is None else hit[0][hit[1]:hit[1] + hit[2]]
 
     def epochs_held(self, lane: int) -> List[int]:
         with self._lock:

@@ -434,35 +434,51 @@ class GatewayHipDecompress(GatewayHipCompress):
         return bytes(h)
 
     def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit) -> Optional[np.ndarray]:
-        """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream."""
+        """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream.  Runs of literal
+        segments and runs of references into one earlier literal stream are each one copy; the only per-segment work is a dictionary look-up."""
         store = self._segment_store()
         segs = rec.segs
+        nseg = len(segs)
         lens = segs["len"].astype(np.int64)
         is_lit = segs["kind"] == dedup_wire.KIND_LITERAL
+        out_end = np.cumsum(lens)
+        out_start = out_end - lens
+        lit_end = np.cumsum(np.where(is_lit, lens, 0))
+        lit_start = lit_end - np.where(is_lit, lens, 0)
+        fpblob = segs["fp"].tobytes()
         lit = lit if isinstance(lit, np.ndarray) else np.frombuffer(lit, np.uint8)
-        lit_ends = np.cumsum(np.where(is_lit, lens, 0))
-        fps = [f.tobytes() for f in segs["fp"]]
         # this chunk's literals first: they may be what its own (or another waiting chunk's) references name
-        idx = np.nonzero(is_lit)[0]
-        store.put_many(rec.lane, rec.epoch, [fps[k] for k in idx], [lit[lit_ends[k] - lens[k]:lit_ends[k]].tobytes() for k in idx])
+        li = np.nonzero(is_lit)[0]
+        if len(li):
+            store.put_chunk(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in li], lit_start[li], lens[li], lit.tobytes())
+        ri = np.nonzero(~is_lit)[0]
+        hits = store.get_many(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in ri]) if len(ri) else []
+        for k, h in zip(ri, hits):
+            if h is None:
+                t0 = self._first_miss.setdefault(cid, time.monotonic())
+                if time.monotonic() - t0 > self.dedup_wait_s:
+                    raise ValueError(f"[Gateway] chunk {cid}: segment {fpblob[16 * k:16 * k + 16].hex()} of lane {rec.lane:#x} epoch {rec.epoch} did not arrive "
+                                     f"within {self.dedup_wait_s:.0f} s (is gpu_decompress running with more than one worker process?)")
+                return None
+            if h[2] != lens[k]:
+                raise ValueError(f"[Gateway] chunk {cid}: referenced segment {fpblob[16 * k:16 * k + 16].hex()} has {h[2]} bytes, the recipe says {int(lens[k])}")
         out = np.empty(rec.raw_len, np.uint8)
-        pos = 0
-        for k in range(len(segs)):
-            n = int(lens[k])
-            if is_lit[k]:
-                out[pos:pos + n] = lit[lit_ends[k] - n:lit_ends[k]]
-            else:
-                seg = store.get(rec.lane, rec.epoch, fps[k])
-                if seg is None:
-                    t0 = self._first_miss.setdefault(cid, time.monotonic())
-                    if time.monotonic() - t0 > self.dedup_wait_s:
-                        raise ValueError(f"[Gateway] chunk {cid}: segment {fps[k].hex()} of lane {rec.lane:#x} epoch {rec.epoch} did not arrive within "
-                                         f"{self.dedup_wait_s:.0f} s (is gpu_decompress running with more than one worker process?)")
-                    return None
-                if len(seg) != n:
-                    raise ValueError(f"[Gateway] chunk {cid}: referenced segment {fps[k].hex()} has {len(seg)} bytes, the recipe says {n}")
-                out[pos:pos + n] = np.frombuffer(seg, np.uint8)
-            pos += n
+        # literal runs: segments k..m literal <=> one contiguous piece of the literal stream
+        if len(li):
+            brk = np.nonzero(np.diff(li) != 1)[0]
+            first, last = np.concatenate([[0], brk + 1]), np.concatenate([brk, [len(li) - 1]])
+            for a, b in zip(li[first], li[last]):
+                out[out_start[a]:out_end[b]] = lit[lit_start[a]:lit_end[b]]
+        # reference runs: neighbours in the chunk that are neighbours in the same earlier literal stream
+        j = 0
+        while j < len(ri):
+            buf, off, n = hits[j]
+            k0, end = ri[j], off + n
+            j += 1
+            while j < len(ri) and ri[j] == ri[j - 1] + 1 and hits[j][0] is buf and hits[j][1] == end:
+                end += hits[j][2]
+                j += 1
+            out[out_start[k0]:out_start[k0] + (end - off)] = np.frombuffer(buf, np.uint8, end - off, off)
         self._first_miss.pop(cid, None)
         return out
 
@@ -522,13 +538,14 @@ class GatewayHipDecompress(GatewayHipCompress):
                 frames[j], raw_lens[j] = rec.lit_frame, rec.lit_raw_len
         dec = [j for j in range(len(todo)) if recipes[j] is None or recipes[j].lit_raw_len]       # (a recipe of references only has nothing to decode)
         want = self.verify_md5 and any(self._expected_digest(chunk_reqs[i]) is not None for i in todo)
-        kwargs = {"want_md5": True} if want else {}
+        want_dec = want and any(recipes[j] is None for j in dec)      # the digest of a literal stream is of no use (and costs a whole MD5 chain)
+        kwargs = {"want_md5": True} if want_dec else {}
         if into is not None:
             kwargs["into"] = [into[j] for j in dec]
         datas, digests = [np.zeros(0, np.uint8)] * len(todo), [None] * len(todo)
         if dec:
             res = ctx.decompress_batch([frames[j] for j in dec], [raw_lens[j] for j in dec], **kwargs)
-            dd, gg = res if want else (res, [None] * len(dec))
+            dd, gg = res if want_dec else (res, [None] * len(dec))
             for j, d, g in zip(dec, dd, gg):
                 datas[j], digests[j] = d, g
         # recipes: rebuild; their digests are those of the rebuilt chunks (one more device call, MD5 only)
