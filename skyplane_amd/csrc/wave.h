@@ -106,7 +106,6 @@ SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(
 // LDS atomics (workgroup scope): ds_min_u32 without return, ds_add_rtn_u32
 SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-SKY_DEV void sky_lds_or_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { return atomicMin(p, v); }
 SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 expect, sky_u64 desired) { return atomicCAS(p, expect, desired); }
 SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -150,9 +149,6 @@ SKY_DEV uint32_t sky_ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, 
 SKY_DEV sky_u64 sky_ld64u(const uint8_t* p) { sky_u64 v; __builtin_memcpy(&v, p, 8); return v; }
 SKY_DEV void sky_st16u(uint8_t* p, uint32_t v) { uint16_t s = (uint16_t)v; __builtin_memcpy(p, &s, 2); }
 SKY_DEV void sky_st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
-
-// ({hi, lo} >> (sh & 31)) & 0xFFFFFFFF: v_alignbit_b32 (a plain 64-bit shift for the host build)
-SKY_DEV uint32_t sky_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((sky_u64)hi << 32) | lo) >> (sh & 31u)); }
 
 struct sky_u128 { uint32_t x, y, z, w; };
 SKY_DEV sky_u128 sky_ld128u(const uint8_t* p) { sky_u128 v; __builtin_memcpy(&v, p, 16); return v; }

@@ -63,7 +63,6 @@ SKY_DEV void sky_wave_fence() { emu_collective(EMU_WAVESYNC, 0, 0); }
 SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
-SKY_DEV void sky_lds_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { sky_u64 o = *p; if (v < o) *p = v; return o; }
 SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 e, sky_u64 d) { sky_u64 o = *p; if (o == e) *p = d; return o; }
 SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
