@@ -281,7 +281,117 @@ def main():
     for cid, d in datas.items():
         assert dst2.get_chunk_file_path(cid).read_bytes() == d, cid
         assert not sidecar.compressed_path(dst2, cid).exists()
-    print(f"OK dropin chunks={len(datas)} wire_bytes={wire} raw_bytes={sum(map(len, datas.values()))}")
+    # ---- 4. dedup on the wire through the same reference classes: gpu_compress(dedup_wire) on the reference's ChunkStore /
+    # GatewayQueue, the patched reference sender ships the recipes it finds where the frames were, the patched reference receiver leaves them as they
+    # arrive, gpu_decompress rebuilds and digest-checks them ----
+    from oracle import ref as oref
+    from skyplane_amd.gateway import dedup_wire
+
+    class EmuDedupContext(EmuContext):
+        def __init__(self, *a):
+            self.cdc, self.gear, self.last = emulib.EmuCdc(16), oref.gear_table(), None
+
+        def process_batch(self, chunks, flags=3, frames_into=None):
+            raw = [bytes(c) for c in chunks]
+            frames, md5s, _ = emulib.process(raw, flags=flags & 3)
+            if flags & 4:
+                prefix, seg_end, fps, first, base, _ = self.cdc.run(raw, self.gear, dedup=bool(flags & 8))
+                self.last = (prefix.astype("uint64"), seg_end, fps, first, base)
+            return [ChunkResult(frame=f if flags & 1 else None, md5=m if flags & 2 else None) for f, m in zip(frames, md5s)]
+
+        def cdc_results(self, n, in_len):
+            return self.last
+
+        def dedup_reset(self):
+            self.cdc = emulib.EmuCdc(16)
+
+    stream = synth.dedup_stream(6 * (256 << 10), dup_fraction=0.5, config_id=3)
+    ddatas = {uuid.uuid4().hex: stream[i * (256 << 10):(i + 1) * (256 << 10)].tobytes() for i in range(6)}
+    src3 = ref_chunk_store.ChunkStore(str(scratch / "src3_chunks"))
+    q3_in, q3_out = ref_queue.GatewayQueue(), ref_queue.GatewayQueue()
+    src3.add_partition("0", q3_in)
+    e3, eq3 = Event(), Queue()
+    op3 = GatewayHipCompress("gpu_compress_0", "local:src", q3_in, q3_out, e3, eq3, src3, n_processes=1, max_batch=3, device_ids=[0], pipeline_depth=1,
+                             dedup_wire=True, context_factory=lambda d, mc, mb: EmuDedupContext())
+    reqs3 = []
+    for cid, d in ddatas.items():
+        src3.get_chunk_file_path(cid).write_bytes(d)
+        cr = ref_chunk.ChunkRequest(chunk=ref_chunk.Chunk(src_key=cid, dest_key=cid, chunk_id=cid, chunk_length_bytes=len(d), partition_id="0"))
+        reqs3.append(cr)
+        assert src3.add_chunk_request(cr)[1]
+    stop3 = threading.Event()
+
+    def drain3(store):
+        while not stop3.is_set():
+            try:
+                store.chunk_status_queue.get(timeout=0.02)
+            except pyqueue.Empty:
+                pass
+
+    threading.Thread(target=drain3, args=(src3,), daemon=True).start()
+    op3.start_workers()
+    done3, t0 = [], time.time()
+    while len(done3) < len(reqs3) and time.time() - t0 < 120 and not e3.is_set():
+        try:
+            done3.append(q3_out.get_nowait())
+        except pyqueue.Empty:
+            time.sleep(0.01)
+    op3.stop_workers()
+    assert not e3.is_set(), eq3.get() if not eq3.empty() else ""
+    payload3 = {cid: sidecar.compressed_path(src3, cid).read_bytes() for cid in ddatas}
+    assert all(dedup_wire.is_recipe(p) for p in payload3.values())
+    plain3 = sum(len(f) for f in emulib.process(list(ddatas.values()), flags=1)[0])
+    wire3 = sum(map(len, payload3.values()))
+    assert wire3 < 0.85 * plain3, (wire3, plain3)
+    dst3 = ref_chunk_store.ChunkStore(str(scratch / "dst3_chunks"))
+    d3_in, d3_out = ref_queue.GatewayQueue(), ref_queue.GatewayQueue()
+    dst3.add_partition("0", d3_in)
+    de3, deq3 = Event(), Queue()
+    receiver3 = rmod.GatewayReceiver("recv", "local:dst", dst3, de3, deq3, use_tls=False, use_compression=True)
+    receiver3.defer_decode = True
+    port3 = receiver3.start_server()
+    dop3 = GatewayHipDecompress("gpu_decompress_0", "local:dst", d3_in, d3_out, de3, deq3, dst3, n_processes=1, max_batch=3, device_ids=[0],
+                                context_factory=lambda d, mc, mb: EmuContext(d, mc, mb))
+    for cr in reqs3:
+        cr.chunk.md5_hash = sidecar.digest_path(src3, cr.chunk.chunk_id).read_text()
+        assert dst3.add_chunk_request(cr)[1]
+
+    def drain3b():
+        while not stop3.is_set():
+            for qq in (dst3.chunk_status_queue, receiver3.socket_profiler_event_queue):
+                try:
+                    qq.get(timeout=0.02)
+                except pyqueue.Empty:
+                    pass
+
+    threading.Thread(target=drain3b, daemon=True).start()
+    dop3.start_workers()
+    sender3 = patched.GatewaySender("send", "local:src", ref_queue.GatewayQueue(), ref_queue.GatewayQueue(), Event(), Queue(), src3, ip_addr="127.0.0.1",
+                                    use_tls=False, use_compression=True, n_processes=1)
+    sender3.worker_id = 0
+    sender3.http_pool = _ControlPlaneStub()
+    sock3 = socket.create_connection(("127.0.0.1", port3))
+    sender3.destination_ports["127.0.0.1"] = port3
+    sender3.destination_sockets["127.0.0.1"] = sock3
+    for cr in reversed(reqs3):            # last chunk first: its references arrive before their literals and must wait for them
+        assert sender3.process(cr, "127.0.0.1") is True
+    done3b, t0 = [], time.time()
+    while len(done3b) < len(reqs3) and time.time() - t0 < 120 and not de3.is_set():
+        try:
+            done3b.append(d3_out.get_nowait())
+        except pyqueue.Empty:
+            time.sleep(0.01)
+    dop3.stop_workers()
+    sock3.close()
+    for p in receiver3.server_processes:
+        p.terminate()
+        p.join(10)
+    stop3.set()
+    assert not de3.is_set(), deq3.get() if not deq3.empty() else ""
+    assert sorted(c.chunk.chunk_id for c in done3b) == sorted(ddatas)
+    for cid, d in ddatas.items():
+        assert dst3.get_chunk_file_path(cid).read_bytes() == d, cid
+    print(f"OK dropin chunks={len(datas)} wire_bytes={wire} raw_bytes={sum(map(len, datas.values()))} dedup_wire={wire3}/{plain3}")
 
 
 if __name__ == "__main__":

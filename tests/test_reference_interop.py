@@ -22,7 +22,7 @@ def test_operator_is_a_drop_in_for_the_reference_classes():
     emulib.lib()
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "_reference_dropin.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, f"{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
-    assert "OK dropin" in p.stdout
+    assert "OK dropin" in p.stdout and "dedup_wire=" in p.stdout      # (step 4: recipes through the reference sender / receiver / queues)
 
 
 def test_checksum_plumbing_and_planner_patches_run_against_the_reference():
