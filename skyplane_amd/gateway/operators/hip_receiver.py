@@ -35,7 +35,8 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
     while True:
         header = WireProtocolHeader.from_socket(conn)
         # the header is untrusted input: bound both lengths before anything is allocated (the reference trusts them, :177-188)
-        if header.raw_data_len > max_chunk_bytes or header.data_len > frame_bound(max_chunk_bytes):
+        # (a dedup recipe -- gateway/dedup_wire.py -- is a frame plus 33 bytes and 21 per segment of at least 1 KiB)
+        if header.raw_data_len > max_chunk_bytes or header.data_len > frame_bound(max_chunk_bytes) + 33 + 21 * (max_chunk_bytes // 1024 + 2):
             raise ValueError(f"[Gateway] chunk {header.chunk_id}: header announces {header.data_len} wire / {header.raw_data_len} raw bytes, limit {max_chunk_bytes}")
         if header.is_compressed and decompress is None:
             # deferred decode: stream the payload to its sidecar in recv_block_size pieces, never holding it whole

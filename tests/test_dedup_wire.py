@@ -252,3 +252,32 @@ def test_dedup_wire_through_sockets_and_both_operator_loops():
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["verified"] is True and res["dedup_wire"] is True
     assert res["wire_ratio"] > 1.45, f"LZ4 alone reaches about 1.3 on this stream; with the duplicates left out: {res['wire_ratio']}"
+
+
+def test_parse_recipe_never_fails_in_any_other_way():
+    """Untrusted input: whatever the bytes, parse_recipe returns a consistent Recipe or raises RecipeError (never an IndexError, a numpy error, ...)."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    rng = np.random.default_rng(5)
+    lens = np.array([300, 400, 50], np.uint32)
+    good = dedup_wire.encode_recipe(1, 2, lens, [0, 1, 0], rng.integers(0, 256, (3, 16), dtype=np.uint8), ref.lz4f_compress_port(bytes(350)), 350)
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.one_of(st.binary(max_size=200), st.tuples(st.integers(0, len(good) - 1), st.integers(0, 255)), st.integers(0, len(good))))
+    def run(x):
+        if isinstance(x, bytes):
+            blob = dedup_wire.MAGIC + x
+        elif isinstance(x, tuple):
+            b = bytearray(good)
+            b[x[0]] = x[1]
+            blob = bytes(b)
+        else:
+            blob = good[:x]
+        try:
+            r = dedup_wire.parse_recipe(blob)
+        except dedup_wire.RecipeError:
+            return
+        assert int(r.segs["len"].sum()) == r.raw_len and len(r.lit_frame) + dedup_wire.HEADER_BYTES + dedup_wire.SEG_BYTES * len(r.segs) == len(blob)
+
+    run()
