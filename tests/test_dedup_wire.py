@@ -281,3 +281,58 @@ def test_parse_recipe_never_fails_in_any_other_way():
         assert int(r.segs["len"].sum()) == r.raw_len and len(r.lit_frame) + dedup_wire.HEADER_BYTES + dedup_wire.SEG_BYTES * len(r.segs) == len(blob)
 
     run()
+
+
+class ArenaEmuDedupContext(EmuDedupContext):
+    """+ SkyHipContext's staging interface over ordinary memory (pinned_buffer / release_pinned / frame_bound, frames_into, into): the operators then take
+    the same zero-copy branches as with the real library -- payloads read into one arena, decoded chunks returned as views of another."""
+
+    def pinned_buffer(self, nbytes):
+        return np.full(nbytes, 0xCD, np.uint8)
+
+    def release_pinned(self, buf):
+        pass
+
+    def frame_bound(self, n):
+        return emulib.frame_bound(n)
+
+    def process_batch(self, chunks, flags=3, frames_into=None):
+        res = super().process_batch(chunks, flags=flags)
+        if frames_into is not None and flags & 1:
+            for r, v in zip(res, frames_into):
+                v[:len(r.frame)] = np.frombuffer(r.frame, np.uint8)
+                r.frame = v[:len(r.frame)]
+        return res
+
+    def decompress_batch(self, frames, raw_lens, want_md5=False, into=None):
+        res = super().decompress_batch(frames, raw_lens, want_md5=want_md5)
+        outs, digs = res if want_md5 else (res, None)
+        if into is not None:
+            assert len(into) == len(outs) and all(v.size >= len(o) for v, o in zip(into, outs))
+            views = []
+            for v, o in zip(into, outs):
+                v[:len(o)] = np.frombuffer(o, np.uint8)
+                views.append(v[:len(o)])
+            outs = views
+        return (outs, digs) if want_md5 else outs
+
+
+def test_staging_branches_with_plain_frames_recipes_and_both_in_one_batch(tmp_path):
+    """The arena (pinned) branches of both operators, as the real library makes them take: a batch of plain frames, a batch of recipes, and a batch that
+    holds both kinds (a deduplicating and a plain source feeding one destination)."""
+    chunks = _dup_chunks(n=6, size=512 << 10)
+    src, dst, reqs = _stores(tmp_path, chunks)
+    comp, dec = _ops(src, dst, ArenaEmuDedupContext(), ArenaEmuDedupContext())
+    plain = GatewayHipCompress("gpu_compress_1", "local:t", GatewayQueue(), GatewayQueue(), Event(), Queue(), src, n_processes=1, max_batch=8,
+                               max_chunk_bytes=4 << 20, device_ids=[0], context_factory=lambda d, mc, mb: ArenaEmuDedupContext())
+    assert all(plain.process_batch(reqs[:2]))            # two chunks as plain frames ...
+    assert all(comp.process_batch(reqs[2:]))             # ... four as recipes
+    kinds = [dedup_wire.is_recipe(sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes()) for cr in reqs]
+    assert kinds == [False, False, True, True, True, True]
+    _ship(src, dst, reqs)
+    assert all(dec.process_batch(reqs[:1]))              # plain only
+    assert all(dec.process_batch(reqs[1:4]))             # plain + recipes
+    assert all(dec.process_batch(reqs[4:]))              # recipes only
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+    assert all("md5_hex" in m for m in dec._last_metadata)
