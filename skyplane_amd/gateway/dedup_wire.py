@@ -18,9 +18,13 @@ Every chunk of a deduplicating lane goes out as a recipe, also one without dupli
 anyway): the destination can only resolve references to segments it has been told about."""
 from __future__ import annotations
 
+import fcntl
+import mmap
+import os
 import struct
 import threading
 from dataclasses import dataclass
+from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -142,6 +146,103 @@ class SegmentStore:
     def epochs_held(self, lane: int) -> List[int]:
         with self._lock:
             return sorted(k[1] for k in self._segs if k[0] == lane)
+
+
+class FileSegmentStore:
+    """The same store for SEVERAL destination worker processes: it lives in files beside the chunks (the gateway's chunk directory is a tmpfs).
+    A chunk's literal stream is one file (written under a temporary name and renamed); every (lane, epoch) has an append-only index of 40-byte
+    records {fingerprint[16], offset u32, length u32, stream id[16]} appended under an advisory lock.  A process keeps the part of an index it has read
+    in a dictionary and reads on from where it stopped when a fingerprint is missing; literal streams are mapped on first use.  Same call surface as
+    SegmentStore (put_chunk / get_many / epochs_held)."""
+
+    _REC = struct.Struct("<16sII16s")
+
+    def __init__(self, directory, keep_epochs: int = 2, max_maps: int = 256):
+        self.dir = Path(directory)
+        self.dir.mkdir(parents=True, exist_ok=True)
+        self.keep_epochs = max(1, int(keep_epochs))
+        self.max_maps = max_maps
+        self._lock = threading.Lock()
+        self._idx: Dict[Tuple[int, int], Tuple[Dict[bytes, Tuple[bytes, int, int]], int]] = {}     # (lane, epoch) -> (fp -> (stream id, off, len), bytes of the index read)
+        self._maps: Dict[bytes, mmap.mmap] = {}
+
+    def _index_path(self, lane: int, epoch: int) -> Path:
+        return self.dir / f"I{lane:016x}-{epoch}.idx"
+
+    def _stream_path(self, lane: int, epoch: int, sid: bytes) -> Path:
+        return self.dir / f"L{lane:016x}-{epoch}-{sid.hex()}.lit"
+
+    def _retire(self, lane: int, epoch: int):
+        for key in [k for k in self._idx if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
+            del self._idx[key]
+        for p in self.dir.glob(f"?{lane:016x}-*"):
+            try:
+                e = int(p.name.split("-")[1].split(".")[0])
+            except ValueError:
+                continue
+            if e + self.keep_epochs <= epoch:
+                try:
+                    p.unlink()
+                except FileNotFoundError:
+                    pass                                   # another worker was faster
+
+    def put_chunk(self, lane: int, epoch: int, fps: List[bytes], offs, lens, litbuf: bytes):
+        sid = os.urandom(16)
+        final = self._stream_path(lane, epoch, sid)
+        tmp = final.with_suffix(".tmp")
+        tmp.write_bytes(litbuf)
+        os.replace(tmp, final)                            # a record never names a stream that is not complete
+        recs = b"".join(self._REC.pack(fp, int(o), int(n), sid) for fp, o, n in zip(fps, offs, lens))
+        with self._lock:
+            self._retire(lane, epoch)
+        with open(self._index_path(lane, epoch), "ab") as f:
+            fcntl.flock(f, fcntl.LOCK_EX)
+            f.write(recs)
+            f.flush()
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+    def _refresh(self, lane: int, epoch: int):
+        d, pos = self._idx.get((lane, epoch), ({}, 0))
+        try:
+            with open(self._index_path(lane, epoch), "rb") as f:
+                f.seek(pos)
+                new = f.read()
+        except FileNotFoundError:
+            new = b""
+        n = len(new) // self._REC.size * self._REC.size    # (a record being appended right now is read next time)
+        for fp, off, ln, sid in self._REC.iter_unpack(new[:n]):
+            d.setdefault(fp, (sid, off, ln))
+        self._idx[(lane, epoch)] = (d, pos + n)
+        return d
+
+    def _map(self, lane: int, epoch: int, sid: bytes):
+        m = self._maps.get(sid)
+        if m is None:
+            with open(self._stream_path(lane, epoch, sid), "rb") as f:
+                size = os.fstat(f.fileno()).st_size
+                m = mmap.mmap(f.fileno(), size, access=mmap.ACCESS_READ) if size else b""
+            if len(self._maps) >= self.max_maps:
+                self._maps.pop(next(iter(self._maps)))
+            self._maps[sid] = m
+        return m
+
+    def get_many(self, lane: int, epoch: int, fps: List[bytes]):
+        with self._lock:
+            d = self._idx.get((lane, epoch), ({}, 0))[0]
+            if any(fp not in d for fp in fps):
+                d = self._refresh(lane, epoch)
+            out = []
+            for fp in fps:
+                h = d.get(fp)
+                out.append(None if h is None else (self._map(lane, epoch, h[0]), h[1], h[2]))
+            return out
+
+    def get(self, lane: int, epoch: int, fp: bytes) -> Optional[bytes]:
+        (hit,) = self.get_many(lane, epoch, [fp])
+        return None if hit is None else bytes(hit[0][hit[1]:hit[1] + hit[2]])
+
+    def epochs_held(self, lane: int) -> List[int]:
+        return sorted({int(p.name.split("-")[1].split(".")[0]) for p in self.dir.glob(f"I{lane:016x}-*.idx")})
 
 
 def classify_segments(prefix, cuts, first, base: int, i: int):

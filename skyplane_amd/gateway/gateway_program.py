@@ -48,10 +48,13 @@ class GatewayGpuCompress(GatewayOperator):
 class GatewayGpuDecompress(GatewayOperator):
     """Destination side: takes the place of GatewayReceive's wait operator when the receiver defers the decode."""
 
-    def __init__(self, num_workers: int = 1, max_batch: int = 32, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False):
+    def __init__(self, num_workers: int = 1, max_batch: int = 32, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False,
+                 dedup_store: str = "memory"):
         super().__init__("gpu_decompress")
-        self.num_workers = 1 if dedup_wire else num_workers      # the segment store lives in one worker process (its lanes share it)
+        # the in-memory segment store lives in one worker process (its lanes share it); "files" puts it into the chunk directory for several
+        self.num_workers = 1 if (dedup_wire and dedup_store == "memory") else num_workers
         self.dedup_wire = dedup_wire
+        self.dedup_store = dedup_store
         self.max_batch = max_batch
         self.max_chunk_mb = max_chunk_mb
         self.verify_md5 = verify_md5
@@ -64,7 +67,8 @@ def create_operator(op: dict, handle: str, region: str, input_queue, output_queu
     if op["op_type"] == "gpu_decompress":
         return GatewayHipDecompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
                                     error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 32),
-                                    max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, verify_md5=op.get("verify_md5", True))      # (recipes are recognised by their magic)
+                                    max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, verify_md5=op.get("verify_md5", True),
+                                    dedup_store=op.get("dedup_store", "memory"))      # (recipes are recognised by their magic)
     if op["op_type"] != "gpu_compress":
         raise ValueError(f"Unsupported op_type {op['op_type']}")   # same failure mode as gateway_daemon.py:267-268
     return GatewayHipCompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,

@@ -407,12 +407,14 @@ class GatewayHipDecompress(GatewayHipCompress):
     GatewayHipCompress; there is no CPU fallback.
     """
 
-    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, **kwargs):
+    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, dedup_store: str = "memory", **kwargs):
         super().__init__(*args, **kwargs)
         self.verify_md5 = verify_md5
+        assert dedup_store in ("memory", "files")
+        self.dedup_store = dedup_store         # "files": the segment store lives in the chunk directory and several worker processes share it
         # dedup on the wire (dedup_wire.py): payloads that are recipes are rebuilt from their literal stream and the segments earlier chunks
-        # brought.  The segment store is shared by the lanes (threads) of ONE worker process: run this operator with n_processes=1 when the
-        # source deduplicates.  A chunk whose references cannot be resolved yet is re-queued; after dedup_wait_s it is an error.
+        # brought.  The default segment store is shared by the lanes (threads) of ONE worker process: run this operator with n_processes=1 when the
+        # source deduplicates, or with dedup_store="files" (FileSegmentStore, shared through the chunk directory) and as many as needed.  A chunk whose references cannot be resolved yet is re-queued; after dedup_wait_s it is an error.
         self.dedup_wait_s = float(dedup_wait_s)
         self._store = None                     # created in the worker process, on the first recipe
         self._store_lock = threading.Lock()
@@ -421,7 +423,10 @@ class GatewayHipDecompress(GatewayHipCompress):
     def _segment_store(self) -> "dedup_wire.SegmentStore":
         with self._store_lock:
             if self._store is None:
-                self._store = dedup_wire.SegmentStore()
+                if self.dedup_store == "files":
+                    self._store = dedup_wire.FileSegmentStore(self.chunk_store.get_chunk_file_path("x").parent / "_segments")
+                else:
+                    self._store = dedup_wire.SegmentStore()
             return self._store
 
     @staticmethod

@@ -336,3 +336,59 @@ def test_staging_branches_with_plain_frames_recipes_and_both_in_one_batch(tmp_pa
     for cr, c in zip(reqs, chunks):
         assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
     assert all("md5_hex" in m for m in dec._last_metadata)
+
+
+def test_file_segment_store_is_shared_between_processes(tmp_path):
+    import multiprocessing as mp
+
+    st = dedup_wire.FileSegmentStore(tmp_path / "seg")
+    st.put_chunk(7, 0, [b"a" * 16, b"b" * 16], [0, 3], [3, 4], b"xyz1234")
+
+    def child(q):
+        other = dedup_wire.FileSegmentStore(tmp_path / "seg")
+        q.put((other.get(7, 0, b"b" * 16), other.get(7, 0, b"c" * 16)))
+        other.put_chunk(7, 0, [b"c" * 16], [0], [2], b"CC")
+
+    q = mp.get_context("fork").Queue()
+    p = mp.get_context("fork").Process(target=child, args=(q,))
+    p.start()
+    assert q.get(timeout=30) == (b"1234", None)
+    p.join(30)
+    assert st.get(7, 0, b"c" * 16) == b"CC"                 # appended by the other process, found by reading the index on
+    hit = st.get_many(7, 0, [b"a" * 16, b"b" * 16])
+    assert hit[0][0] is hit[1][0] and (hit[0][1], hit[0][2], hit[1][1], hit[1][2]) == (0, 3, 3, 4)      # one mapping per literal stream: runs stay runs
+    st.put_chunk(7, 2, [b"d" * 16], [0], [1], b"D")
+    assert st.epochs_held(7) == [2] and not list((tmp_path / "seg").glob("L*-0-*"))                      # epoch 0 retired, its files gone
+
+
+def test_dedup_wire_two_destination_worker_processes_share_the_file_store(tmp_path):
+    """gpu_decompress(dedup_store="files", n_processes=2): whichever worker gets a chunk finds the segments the other one stored."""
+    import queue as pyqueue
+    import time
+
+    chunks = _dup_chunks(n=8, size=256 << 10)
+    src, dst, reqs = _stores(tmp_path, chunks)
+    comp, _ = _ops(src, dst, EmuDedupContext(), EmuDedupContext())
+    assert all(comp.process_batch(reqs))
+    _ship(src, dst, reqs)
+    ee, eq = Event(), Queue()
+    q_in, q_out = GatewayQueue(), GatewayQueue()
+    dst.add_partition("0", q_in)
+    dec = GatewayHipDecompress("gpu_decompress_0", "local:t", q_in, q_out, ee, eq, dst, n_processes=2, max_batch=2, max_chunk_bytes=4 << 20, device_ids=[0],
+                               pipeline_depth=1, dedup_store="files", context_factory=lambda d, mc, mb: EmuDedupContext())
+    for cr in reversed(reqs):
+        q_in.put(cr)
+    dec.start_workers()
+    done, t0 = [], time.time()
+    while len(done) < len(reqs) and time.time() - t0 < 120 and not ee.is_set():
+        try:
+            done.append(q_out.get_nowait())
+        except pyqueue.Empty:
+            time.sleep(0.01)
+    dec.stop_workers()
+    assert not ee.is_set(), eq.get() if not eq.empty() else ""
+    assert len(done) == len(reqs)
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+    d = gateway_program.GatewayGpuDecompress(num_workers=4, dedup_wire=True, dedup_store="files").to_dict()
+    assert d["num_workers"] == 4 and d["dedup_store"] == "files"
