@@ -396,3 +396,10 @@ def main():
 
 if __name__ == "__main__":
     main()
+    # the reference's logger and the drain threads above are daemon threads that may hold stderr's lock at interpreter shutdown ("could not acquire
+    # lock for <stderr> at interpreter shutdown" = exit code -6 after a successful run): everything is verified and printed, leave without the teardown
+    sys.stdout.flush()
+    sys.stderr.flush()
+    import os
+
+    os._exit(0)

@@ -296,3 +296,8 @@ if __name__ == "__main__":
     n = f3()
     ops = f4()
     print(f"OK f3 chunks={n} f4 program={'>'.join(ops)}")
+    sys.stdout.flush()       # (daemon threads of the reference's logger may hold stderr's lock at interpreter shutdown: leave without the teardown, as _reference_dropin.py)
+    sys.stderr.flush()
+    import os
+
+    os._exit(0)

@@ -32,6 +32,10 @@ typedef struct { uint32_t n_rec, n_kept, n_trimmed, n_dropped, n_probe_fail; } l
 // Compress one block of n <= 65536 bytes.  Returns the compressed size; writes the block when dst != NULL
 // (dst must hold n + n/255 + 16 bytes).  recs_out (optional, 16 * LZ4S_LANES words) receives the raw per-slice records.
 uint32_t* lz4s_dbg_visits = 0;   /* optional: LZ4S_LANES words, visits made per slice (load statistics for kernel tuning) */
+/* optional trace of every visit, for the LDS cost model of the kernel's parse (scripts/dev/lz4s_cost_model.py): one word per visit,
+   slice | visit number << 10 | valid table candidates (bit per region) << 14 | 16-byte extension steps << 18; lz4s_dbg_ntrace counts them */
+uint32_t* lz4s_dbg_trace = 0;
+uint32_t lz4s_dbg_trace_cap = 0, lz4s_dbg_ntrace = 0;
 uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats* st) {
     const uint32_t NB = 1u << LZ4S_LOGB;
     uint32_t* T = (uint32_t*)malloc((size_t)NB * LZ4S_Q * 4);
@@ -60,7 +64,7 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                 const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
                 const uint32_t q = p >> LZ4S_RLOG, tb = LZ4S_TAG(x) << 16, rel = p & ((1u << LZ4S_RLOG) - 1u);
                 const uint32_t* e = &T[LZ4S_BUCKET(x) * LZ4S_Q];
-                uint32_t best = 0, bc = 0;
+                uint32_t best = 0, bc = 0, validmask = 0, extsteps = 0;
                 int cand = 0;
                 const uint32_t cap8 = lim - p < 8u ? lim - p : 8u;
                 // short-period candidate (runs, "abab", 32-bit patterns): the 4 bytes before p repeat at p.  Overlapping
@@ -71,12 +75,18 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                     const uint32_t d = e[k] - tb;
                     if (!((uint32_t)k < q ? d < 0x10000u : d < rel)) continue;
                     cand = 1;
+                    validmask |= 1u << k;
                     const uint32_t c = ((uint32_t)k << LZ4S_RLOG) + d;
                     const uint32_t l = common(s + p, s + c, cap8);
                     if (l >= 4u && (l > best || (l == best && c > bc))) { best = l; bc = c; }
                 }
+                const uint32_t this_visit = visits;
                 if (cand) visits++;                                   // a position with a candidate by tag (or a period hit) is a visit of the lane
-                if (!best) { z.n_probe_fail++; continue; }            // tag hit that does not verify (or no candidate): a literal
+                if (!best) {                                          // tag hit that does not verify (or no candidate): a literal
+                    if (cand && lz4s_dbg_trace && lz4s_dbg_ntrace < lz4s_dbg_trace_cap) lz4s_dbg_trace[lz4s_dbg_ntrace++] = j | this_visit << 10 | validmask << 14;
+                    z.n_probe_fail++;
+                    continue;
+                }
                 uint32_t len = best;
                 if (len == 8u) {
                     while (p + len < lim) {
@@ -85,7 +95,9 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                         len += t;
                         if (t < 8u) break;
                     }
+                    extsteps = (len - 8u + 15u) / 16u + (p + len < lim && ((len - 8u) & 15u) == 0u ? 1u : 0u);   /* 16-byte steps the kernel takes: the last one finds the mismatch (or the limit) */
                 }
+                if (lz4s_dbg_trace && lz4s_dbg_ntrace < lz4s_dbg_trace_cap) lz4s_dbg_trace[lz4s_dbg_ntrace++] = j | this_visit << 10 | validmask << 14 | (extsteps > 16383u ? 16383u : extsteps) << 18;
                 // move the start back over pending literals: at most LZ4S_BACK bytes, 4 when the match is the distance-4 one (the kernel has the
                 // 8 bytes before every table candidate in registers, but only 4 of the 8 before position p - 4)
                 const uint32_t backmax = bc + 4u == p ? 4u : LZ4S_BACK;
