@@ -392,3 +392,18 @@ def test_dedup_wire_two_destination_worker_processes_share_the_file_store(tmp_pa
         assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
     d = gateway_program.GatewayGpuDecompress(num_workers=4, dedup_wire=True, dedup_store="files").to_dict()
     assert d["num_workers"] == 4 and d["dedup_store"] == "files"
+
+
+def test_recipe_format_is_pinned_by_a_golden_vector():
+    """tests/golden/recipe_v1.bin (tests/golden/make_recipe_golden.py): the encoder still produces it byte for byte and the parser reads it back."""
+    from pathlib import Path
+
+    from tests.golden import make_recipe_golden
+
+    want = (Path(__file__).parent / "golden" / "recipe_v1.bin").read_bytes()
+    blob, lit = make_recipe_golden.build()
+    assert blob == want
+    r = dedup_wire.parse_recipe(want)
+    assert (r.lane, r.epoch, r.raw_len, r.lit_raw_len, len(r.segs)) == (0x0123456789ABCDEF, 3, 25052, 18908, 5)
+    assert r.segs["kind"].tolist() == [0, 1, 0, 0, 1] and ref.lz4f_decode(bytes(r.lit_frame), r.lit_raw_len)[0] == lit
+    assert want[:5] == b"SKYD\x01" and want[5:13] == bytes.fromhex("efcdab8967452301")
