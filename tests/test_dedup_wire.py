@@ -407,3 +407,20 @@ def test_recipe_format_is_pinned_by_a_golden_vector():
     assert (r.lane, r.epoch, r.raw_len, r.lit_raw_len, len(r.segs)) == (0x0123456789ABCDEF, 3, 25052, 18908, 5)
     assert r.segs["kind"].tolist() == [0, 1, 0, 0, 1] and ref.lz4f_decode(bytes(r.lit_frame), r.lit_raw_len)[0] == lit
     assert want[:5] == b"SKYD\x01" and want[5:13] == bytes.fromhex("efcdab8967452301")
+
+
+def test_dedup_wire_ragged_and_empty_chunks(tmp_path):
+    """Chunks below the smallest segment, an empty one, one that is a single run, one made of nothing but copies of an earlier one."""
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes()
+    chunks = [b"", b"tiny", base, bytes(50_000), base, base[:1023], base[5:40_000] + base[:3]]
+    src, dst, reqs = _stores(tmp_path, chunks)
+    comp, dec = _ops(src, dst, EmuDedupContext(), EmuDedupContext())
+    assert all(comp.process_batch(reqs))
+    recs = [dedup_wire.parse_recipe(sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes()) for cr in reqs]
+    assert len(recs[0].segs) == 0 and recs[0].raw_len == 0
+    assert recs[4].lit_raw_len == 0 and recs[4].segs["kind"].all(), "the second copy of a chunk is references only"
+    _ship(src, dst, reqs)
+    assert all(dec.process_batch(reqs))
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
