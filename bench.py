@@ -79,6 +79,21 @@ def _w_md5(args):
     return lo, out
 
 
+def _w_frames(args):
+    """Frames of one verification round (packed in the shared arena `which`): each must decode, with liblz4 -- the library behind the
+    reference's lz4.frame.decompress (gateway_receiver.py:195-201) --, to exactly the chunk it was made from."""
+    which, items, rots, xor_tiles = args
+    from oracle import ref
+
+    arena, cb = _G["arena"][which], _G["cb"]
+    for i, off, ln in items:
+        a, b = chunk_view(i, rots, xor_tiles)
+        dec = ref.lz4f_decompress(arena[off:off + ln], cb)
+        if len(dec) != cb or dec[:a.size] != a.tobytes() or dec[a.size:] != b.tobytes():
+            return i
+    return -1
+
+
 def _w_baseline(args):
     """The reference CPU path restated exactly: per chunk lz4.frame.compress(data) (system liblz4 through oracle.ref, python-lz4's
     default preferences; gateway_operator.py:359) then hashlib.md5(data).digest() (s3_interface.py:181-192)."""
@@ -155,6 +170,20 @@ class EmuContext:
         pass
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: re-execute this very command line as N ranks of one node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 -- the container's hostname may not resolve)."""
+    import socket
+
+    with socket.socket() as sk:          # a free port chosen by the kernel
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,8 +199,11 @@ def main():
     ap.add_argument("--verify", choices=["full", "sample", "none"], default="full", help="post-run check of digests (all / 64 chunks) and of sampled frames")
     ap.add_argument("--context", choices=["hip", "emu"], default="hip", help="emu = CPU emulator + gloo (tests of this file's rank logic only)")
     ap.add_argument("--chunk-bytes", type=int, default=synth.CHUNK_BYTES, help="tests only; the metric is defined on 8 MiB chunks")
+    ap.add_argument("--halves", type=int, default=0, help="tests only: resident halves per step (0 = 2 when the stream has more than 8192 chunks)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)      # bare `python bench.py --gpus N`: become N ranks (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,6 +229,13 @@ def main():
         cores = max(1, min(cores, int(quota + 0.5)))
     want_cpu = rank == 0 and not args.no_cpu_baseline
     pool_n = cores if want_cpu else max(1, cores // world)
+    # two shared arenas (anonymous shared mappings, made before the fork) carry the frames of a verification round to the workers
+    bound_h = 15 + cb + 4 * ((cb + 65535) // 65536) + 4
+    round_n = max(1, min(128, (1 << 30) // bound_h))
+    if args.verify != "none":
+        import mmap
+
+        _G["arena"] = [np.frombuffer(mmap.mmap(-1, round_n * bound_h), np.uint8) for _ in range(2)]
     pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None
 
     import torch  # noqa: E402  (imported before libskyhip so both share one HIP runtime; no device touched before the fork above)
@@ -220,7 +259,7 @@ def main():
 
     bound = 15 + cb + 4 * ((cb + 65535) // 65536) + 4 if emu else hip_ops.frame_bound(cb)
     stride = (bound + 255) & ~255
-    halves = 2 if (n_target > 8192 and not args.cdc) else 1          # frame slots are reused by the second half
+    halves = args.halves or (2 if (n_target > 8192 and not args.cdc) else 1)          # frame slots are reused by the second half
     n_chunks = n_target
     if not emu:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
@@ -259,6 +298,7 @@ def main():
     in_len = np.full(n_chunks, cb, np.uint64)
     out_off = np.arange(n_half, dtype=np.uint64) * stride
     out_cap = np.full(n_half, stride, np.uint64)
+    out_off_all, out_cap_all = np.tile(out_off, halves), np.tile(out_cap, halves)
 
     if emu:
         ctx = EmuContext()
@@ -272,12 +312,9 @@ def main():
     def step():
         if args.cdc:
             ctx.dedup_reset()      # every step sees the stream for the first time
-        lens, digs = [], []
-        for h in range(halves):
-            sl = slice(h * n_half, (h + 1) * n_half)
-            ol, md = ctx.process_device(p_in, in_off[sl], in_len[sl], p_out, out_off, out_cap, flags)
-            lens.append(ol); digs.append(md)
-        last["out_len"], last["md5"] = np.concatenate(lens), np.concatenate(digs)
+        # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the LZ4
+        # sub-batches of both halves; the second half's frames take over the first half's slots (s_fr orders the writes)
+        last["out_len"], last["md5"] = ctx.process_device(p_in, in_off, in_len, p_out, out_off_all, out_cap_all, flags)
 
     def sync():
         if not emu:
@@ -289,6 +326,13 @@ def main():
     _local, elapsed = shard.timed_region(step, args.steps, dist=dist, sync=sync)      # barrier + synchronize on both sides, MAX over ranks
     tm = ctx.timing()
     out_len, md5 = last["out_len"], last["md5"]
+    # the second roofline (min(HBM, chain)): MD5 is one serial chain per chunk, so a step can never be shorter than one chain however
+    # many lanes idle.  Measured, outside the timed region: the digest kernel alone over the same resident chunks.
+    md5_alone_ms = None
+    if not emu and rank == 0:
+        ctx.reset_timing()
+        ctx.process_device(p_in, in_off, in_len, p_out, out_off_all, out_cap_all, hip_ops.F_MD5)
+        md5_alone_ms = ctx.timing().md5_ms
 
     # ---- verification, outside the timed region: every digest of the last step, a sample of the frames of its last half ----
     verified = {"digests": 0, "frames": 0}
@@ -299,14 +343,38 @@ def main():
             for k, d in enumerate(digs):
                 assert md5[lo + k].tobytes() == d, f"rank {rank}: md5 of chunk {lo + k} differs from hashlib"
         verified["digests"] = len(idx)
-        from oracle import ref
+        # every frame still resident (all of them; with two halves the second half, whose frames replaced the first's in the slots): D2H into
+        # a shared arena round by round (double buffered), decoded and compared by the pool while the next round is copied
+        js = list(range(n_half)) if args.verify == "full" else sorted(set(np.linspace(0, n_half - 1, 24).astype(int).tolist()))
+        arenas = [torch.from_numpy(a) for a in _G["arena"]]
+        if not emu:
+            for a in arenas:      # page-lock the arenas for asynchronous D2H (best effort: pageable copies work too)
+                try:
+                    torch.cuda.cudart().cudaHostRegister(a.data_ptr(), a.numel(), 0)
+                except Exception:
+                    pass
+        pending = None
 
-        for j in sorted(set(np.linspace(0, n_half - 1, 24).astype(int).tolist())):
-            i = (halves - 1) * n_half + j
-            a, b = chunk_view(i, rots, args.cdc)
-            f = d_out[int(out_off[j]):int(out_off[j]) + int(out_len[i])].cpu().numpy()
-            assert ref.lz4f_decompress(f, cb) == a.tobytes() + b.tobytes(), f"rank {rank}: frame of chunk {i} does not decode to the chunk (liblz4)"
-            verified["frames"] += 1
+        def reap(p):
+            for bad in p.get():
+                assert bad < 0, f"rank {rank}: frame of chunk {bad} does not decode to the chunk (liblz4)"
+
+        for r0 in range(0, len(js), round_n):
+            which = (r0 // round_n) & 1
+            items, o = [], 0
+            for j in js[r0:r0 + round_n]:
+                i = (halves - 1) * n_half + j
+                ln = int(out_len[i])
+                arenas[which][o:o + ln].copy_(d_out[int(out_off[j]):int(out_off[j]) + ln], non_blocking=True)
+                items.append((i, o, ln)); o += ln
+            sync()
+            if pending is not None:
+                reap(pending)
+            per = max(1, (len(items) + pool_n - 1) // pool_n)
+            pending = pool.map_async(_w_frames, [(which, items[k:k + per], rots, args.cdc) for k in range(0, len(items), per)], chunksize=1)
+            verified["frames"] += len(items)
+        if pending is not None:
+            reap(pending)
     dd = hashlib.md5(md5.tobytes()).hexdigest()      # digest of digests of this rank's stream
     ok = 1
     if world > 1:
@@ -344,6 +412,15 @@ def main():
             "verified": {"digests_vs_hashlib": verified["digests"], "frames_vs_liblz4": verified["frames"], "digest_of_digests": dd, "all_ranks_ok": bool(ok)},
             "setup_s": round(gen_s, 1),
         }
+        if md5_alone_ms:
+            hbm_in = HBM_PEAK_GBPS * 1e9 / (1.0 + comp_bytes / (n_chunks * cb)) / 2**30      # input GiB/s at which N + C bytes saturate the HBM peak
+            chain = n_chunks * cb / (md5_alone_ms / 1e3) / 2**30
+            res["roofline"]["chain"] = {
+                "kernel": "sky_md5_chunks", "md5_alone_ms": round(md5_alone_ms, 3), "per_chain_MBps": round(cb / (md5_alone_ms / 1e3) / 1e6, 2),
+                "resident_chains": int(n_chunks), "bound_GiBps": round(chain, 1), "hbm_bound_GiBps": round(hbm_in, 1),
+                "min_bound": "chain" if chain < hbm_in else "hbm", "frac_of_min_bound": round(value / world / min(chain, hbm_in), 4),
+                "note": "whole-chunk MD5 is a serial dependency chain per chunk (RFC 1321): with every chunk of the step resident and hashed concurrently the "
+                        "step cannot be shorter than one chain; bound = resident chains x measured per-chain rate (rank 0's GPU)"}
         # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (scripts/pmc.sh); a committed measurement is
         # quoted only for the kernel and stream it was taken on
         tf = ROOT / "profiles" / "traffic.json"

@@ -413,6 +413,28 @@ def test_bench_py_rank_logic_world2_gloo():
     assert r["value"] > 0 and abs(r["value"] - 2 * 8 * 131072 * 2 / (r["ms_per_step"] * 2 / 1e3) / 2**30) < 0.01 * r["value"] + 1e-3
 
 
+def test_bench_py_bare_gpus2_launches_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the shape the driver uses for --gpus 1) must become two ranks on its own and print
+    one JSON line; run with two resident halves so that the second half's frames replace the first's in the slots (configs[3])."""
+    import json
+    import subprocess
+    import sys
+
+    from tests.emu import emulib
+    emulib.lib()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--context", "emu", "--chunk-bytes", "131072", "--chunks", "8", "--unit-mib", "1",
+           "--steps", "1", "--warmup", "0", "--max-batch", "2", "--halves", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["chunks_per_gpu"] == 8 and "2 resident half" in r["config"]["workload"]
+    # every digest of the step, every frame still resident (the second half's) checked on every rank
+    assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 8 and r["verified"]["frames_vs_liblz4"] == 4
+
+
 def test_steady_state_e2e_script_with_emulated_device():
     """scripts/e2e_steady.py end to end on the CPU: both operators run the shipping kernel source under the emulator;
     sender threads, loopback TCP, deferred receiver, digest registration and the final verification are the real thing."""
