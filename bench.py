@@ -394,7 +394,7 @@ def main():
         # chunk; the 16-byte digest and cut offsets are negligible), divided by the HIP-event duration of that kernel on the library's stream.
         lz4_s = tm.lz4_ms / 1e3
         achieved = (tm.lz4_in_bytes + tm.lz4_out_bytes) / lz4_s / 1e9 if lz4_s > 0 else 0.0
-        kname = "sky_lz4_compress" if os.environ.get("SKYHIP_LZ4_KERNEL") == "wave" else "sky_lz4s_compress"
+        kname = "sky_lz4s_compress"
         res = {
             "metric": "GiB/s through compress+hash stage (input bytes)", "value": round(value, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

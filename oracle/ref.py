@@ -136,7 +136,7 @@ def gear_table() -> np.ndarray:
     return t
 
 
-# Frozen CDC parameters (ours; not in the reference): 4 KiB / 16 KiB / 64 KiB, masks on high bits.
+# Frozen CDC parameters (ours; not in the reference): min / avg / max = 1 KiB / 4 KiB / 16 KiB, masks on high bits.
 CDC_MIN, CDC_AVG, CDC_MAX = 1024, 4096, 16384
 CDC_MASK_S = 0xFFFC000000000000  # 14 bits: harder, used before the average size
 CDC_MASK_L = 0xFFC0000000000000  # 10 bits: easier, used after it (subset of MASK_S)

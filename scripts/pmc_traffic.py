@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only -- see scripts/gpu_r2z2.sh) over
+"""Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only -- scripts/pmc.sh) over
 scripts/dev/lz4s_exp.py to bytes per launch of the dominant kernel and per input byte, and write profiles/traffic.json entries.
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 bytes per
 lane); other access widths and WRITE_SIZE are uncalibrated (MI355X_MICROARCH.md, HBM section).  This kernel's one wide streaming read is the input

@@ -13,7 +13,7 @@
 #include "skyhip.h"
 #include "wave.h"
 #include "skyhip_kernels.h"
-#include "lz4_kernel.inc"
+#include "lz4_common.inc"
 #include "lz4s_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
@@ -25,10 +25,6 @@
 // ------------------------------------------------------------------------------------------------
 // __global__ wrappers around the portable kernel bodies
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(SKY_LZ4_WAVES * 64) sky_lz4_compress(SkyLz4Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    sky_lz4_compress_body(a, smem);
-}
 #ifndef LZ4S_KERNEL_ATTR
 // 5 waves per SIMD = 96 VGPRs: a compressor workgroup puts 4 waves on every SIMD of its CU, so one more wave of another kernel (MD5, frame
 // gather) fits beside it.  At the 128 VGPRs the launch bound alone would allow, the compressor runs 3 % faster alone but nothing else can
@@ -167,7 +163,6 @@ struct skyhip_ctx {
                                   // workgroups, 187 ms as 256-lane, 374 ms as 512-lane ones (profiles/r2_md5_workgroup.txt).  SKYHIP_MD5_WG overrides.
     bool md5_wg_env = false;      // SKYHIP_MD5_WG given: no automatic choice
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
-    bool lz4_wave_kernel = false; // SKYHIP_LZ4_KERNEL=wave: the round-1 wave-per-block compressor (kept for A/B measurements)
     DevBuf<sky_u64> d_blk_dst[2];
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
     DevBuf<uint8_t> d_stage_in, d_stage_out;
@@ -311,28 +306,20 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
             HIPCHK(c, c->d_blk_word[k].ensure(nb));
             HIPCHK(c, c->d_blk_dst[k].ensure(nb));
         }
-        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_compress, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
         HIPCHK(c, c->d_queue.ensure(16));
         { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) { c->md5_wg = v; c->md5_wg_env = true; } }
-        { const char* e = getenv("SKYHIP_LZ4_KERNEL"); c->lz4_wave_kernel = e && !strcmp(e, "wave"); }
 #ifdef SKY_WITH_CDC
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
 #endif
         if (getenv("SKYHIP_DEBUG")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sky_lz4_compress, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES);
-            hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, (const void*)sky_lz4_compress);
             int nbs = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, (const void*)sky_lz4s_compress, LZ4S_LANES, LZ4S_LDS_BYTES);
             hipFuncAttributes fs;
             (void)hipFuncGetAttributes(&fs, (const void*)sky_lz4s_compress);
             fprintf(stderr, "[skyhip] sky_lz4s_compress: %d workgroups/CU (x16 waves), %d VGPRs, %u B dynamic LDS, grid %d\n", nbs, fs.numRegs, (unsigned)LZ4S_LDS_BYTES, c->lz4s_grid);
-            fprintf(stderr, "[skyhip] sky_lz4_compress: %d workgroups/CU (x%d waves), %d VGPRs, %zu B static LDS, %d B dynamic LDS, CUs %d, LDS/CU %zu\n", nb,
-                    SKY_LZ4_WAVES, fa.numRegs, fa.sharedSizeBytes, SKY_LZ4_LDS_BYTES, prop.multiProcessorCount, prop.maxSharedMemoryPerMultiProcessor);
         }
         return 0;
     }();
@@ -500,10 +487,9 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
             EvPair ep;
             if (nb) {
                 if (sub >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, c->ev_fr_done[bf], 0));     // the frames of sub-batch sub-2 have left this buffer
-                if (!c->lz4_wave_kernel) HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4, c->s_lz4));     // block queue head
+                HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4, c->s_lz4));     // block queue head
                 if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
-                if (c->lz4_wave_kernel) hipLaunchKernelGGL(sky_lz4_compress, dim3((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES), dim3(SKY_LZ4_WAVES * 64), SKY_LZ4_LDS_BYTES, c->s_lz4, la);
-                else hipLaunchKernelGGL(sky_lz4s_compress, dim3(nb < (uint32_t)c->lz4s_grid ? nb : (uint32_t)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_BYTES, c->s_lz4, la);
+                hipLaunchKernelGGL(sky_lz4s_compress, dim3(nb < (uint32_t)c->lz4s_grid ? nb : (uint32_t)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_BYTES, c->s_lz4, la);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
                 c->tm.lz4_launches++; c->tm.lz4_in_bytes += sub_bytes;

@@ -5,13 +5,6 @@
 
 #define SKY_LZ4_BLOCK 65536u     // LZ4 frame BD=4: 64 KiB blocks (what python-lz4's default emits)
 #define SKY_LZ4_SLOT 66048u      // per-block scratch slot >= LZ4_COMPRESSBOUND(65536) = 65809, 512-aligned
-#ifndef SKY_HASH_LOG
-#define SKY_HASH_LOG 12          // 4096-entry table, same size class as liblz4's streaming table
-#endif
-#ifndef SKY_LZ4_WAVES
-#define SKY_LZ4_WAVES 4          // waves (= blocks) per workgroup: 4 x 8 KiB tables = 32 KiB LDS -> 5 workgroups per CU
-#endif
-#define SKY_LZ4_LDS_BYTES (SKY_LZ4_WAVES * (2u << SKY_HASH_LOG))
 
 #define SKY_FRAME_HDR 15u        // magic 4 + FLG + BD + content size 8 + HC
 #define SKY_FRAME_FLG 0x68u      // version 01, block-independent, content size present

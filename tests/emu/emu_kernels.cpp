@@ -7,7 +7,7 @@
 
 #include "wave.h"          // picks up emu.h because SKY_EMU is defined
 #include "skyhip_kernels.h"
-#include "lz4_kernel.inc"
+#include "lz4_common.inc"
 #include "lz4s_kernel.inc"
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
@@ -16,7 +16,6 @@
 #include "gear_kernel.inc"
 #endif
 
-static void k_lz4(void* a, uint8_t* smem) { sky_lz4_compress_body(*(SkyLz4Args*)a, smem); }
 static void k_lz4s(void* a, uint8_t* smem) { sky_lz4s_compress_body(*(SkyLz4Args*)a, smem); }
 static void k_md5(void* a, uint8_t*) { sky_md5_body(*(SkyMd5Args*)a); }
 static void k_layout(void* a, uint8_t*) { sky_frame_layout_body(*(SkyFrameArgs*)a); }
@@ -51,8 +50,7 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         const int grid = nb < 3u ? (int)nb : 3;      // a persistent grid smaller than the block count: every workgroup walks several blocks
         uint32_t qhead = 0;
         la.queue = &qhead;
-        if (flags & 0x100u) { if (nb) emu_launch((nb + SKY_LZ4_WAVES - 1) / SKY_LZ4_WAVES, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la); }   // the wave-per-block kernel
-        else if (nb) emu_launch(grid, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
+        if (nb) emu_launch(grid, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s, &la);
         SkyFrameArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.blk_prefix = prefix.data(); fa.n_chunks = (uint32_t)n;
         fa.n_blocks = nb; fa.scratch = scratch.data(); fa.csize = csize.data(); fa.out = out; fa.out_off = ooff.data(); fa.frame_len = flen.data();
         fa.blk_dst = bdst.data(); fa.blk_word = word.data();
@@ -62,15 +60,6 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         if (csize_out) for (uint32_t b = 0; b < nb; b++) csize_out[b] = csize[b];
     }
     return 0;
-}
-
-// raw single-block entry (no frame): returns compressed size
-uint32_t emu_lz4_block(const uint8_t* src, uint32_t n, uint8_t* dst /* SKY_LZ4_SLOT bytes */) {
-    sky_u64 off = 0; uint32_t len = n; uint32_t prefix[2] = {0, 1}; uint32_t cs = 0;
-    SkyLz4Args la; la.in = src; la.in_off = &off; la.in_len = &len; la.blk_prefix = prefix; la.n_chunks = 1; la.n_blocks = 1; la.scratch = dst; la.csize = &cs; la.ablate = 0; la.prof = nullptr;
-    la.queue = nullptr;
-    emu_launch(1, SKY_LZ4_WAVES * 64, SKY_LZ4_LDS_BYTES, k_lz4, &la);
-    return cs;
 }
 
 // the slice-parallel kernel on one block; dst = SKY_LZ4_SLOT bytes, written only when the block shrinks.  Returns the size.

@@ -21,8 +21,6 @@ def lib() -> C.CDLL:
         l = C.CDLL(str(_SO))
         l.emu_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         l.emu_process.restype = C.c_int
-        l.emu_lz4_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-        l.emu_lz4_block.restype = C.c_uint32
         l.emu_slot_bytes.restype = C.c_uint32
         l.emu_decompress.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5
         l.emu_decompress.restype = C.c_int
