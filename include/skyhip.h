@@ -94,6 +94,13 @@ int  skyhip_process_batch(skyhip_ctx* ctx, int n,
  * Blocks still alive at skyhip_destroy are freed there. */
 int  skyhip_host_alloc(skyhip_ctx* ctx, size_t bytes, void** out);
 int  skyhip_host_free(skyhip_ctx* ctx, void* p);
+/* Page-lock memory the CALLER owns -- in the gateway: a MAP_SHARED mapping of an arena file in the chunk directory (tmpfs), the shared-memory
+ * hand-off between gpu_compress and the sender ("pinned shared memory instead of tmpfs files"; replaces the per-chunk
+ * `<id>.chunk.lz4f` file the sender read back with `f.read()`, gateway_operator.py:350-351).  Frames then travel device -> arena by DMA and
+ * arena -> socket by sendfile: no CPU copy in between.  The range must stay mapped until skyhip_host_unregister (skyhip_destroy unregisters what
+ * is left).  Registering is expensive (pages are pinned): do it once per arena, not per chunk. */
+int  skyhip_host_register(skyhip_ctx* ctx, void* p, size_t bytes);
+int  skyhip_host_unregister(skyhip_ctx* ctx, void* p);
 
 /* Device-resident batch (kernel-only path: inputs already in HBM, PCIe excluded).
  * d_in / d_out are DEVICE pointers on ctx's device; in_off/in_len/out_off/out_cap are HOST arrays of

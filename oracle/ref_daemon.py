@@ -54,7 +54,10 @@ SENDER_EDITS = [
     ('            with open(chunk_file_path, "rb") as f:\n                data = f.read()\n',
      '            lz4f_path = chunk_file_path.with_name(chunk_file_path.name + ".lz4f")\n'
      '            precompressed = lz4f_path.exists()                      # produced by gpu_compress\n'
-     '            with open(lz4f_path if precompressed else chunk_file_path, "rb") as f:\n                data = f.read()\n'),
+     '            with open(lz4f_path if precompressed else chunk_file_path, "rb") as f:\n                data = f.read()\n'
+     '            if precompressed:                                       # a frame, or a pointer into gpu_compress\'s shared arena\n'
+     '                from skyplane_amd.gateway.shm_arena import take_payload\n'
+     '                data = take_payload(lz4f_path, data)\n'),
     ('            assert len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size',
      '            assert precompressed or len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size'),
     ('            raw_wire_length = wire_length\n', '            raw_wire_length = chunk.chunk_length_bytes if precompressed else wire_length\n'),

@@ -36,10 +36,11 @@ from skyplane_amd.gateway.operators import hip_receiver, hip_sender  # noqa: E40
 from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress, GatewayHipDecompress  # noqa: E402
 
 
-def receiver_main(dst_dir, port_q, done_q, n_conn):
+def receiver_main(dst_dir, port_q, done_q, n_conn, arena_slots=0, max_chunk_bytes=0):
     """Destination gateway's receiver stand-in: one process, one thread per connection, no GPU -- the decode is the
     gpu_decompress operator's job (hip_receiver.recv_chunks(decompress=None))."""
     store = ChunkStore(dst_dir)
+    arena = hip_receiver.make_arena(store, "e2e", max_chunk_bytes, arena_slots) if arena_slots else None     # shared-memory hand-off to gpu_decompress
     srv = socket.socket()
     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     srv.bind(("127.0.0.1", 0))
@@ -48,7 +49,7 @@ def receiver_main(dst_dir, port_q, done_q, n_conn):
 
     def serve(conn):
         with conn:
-            done_q.put(hip_receiver.recv_chunks(conn, store, None))
+            done_q.put(hip_receiver.recv_chunks(conn, store, None, arena=arena))
 
     threads = []
     for _ in range(n_conn):

@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--workers", type=int, default=1)
     ap.add_argument("--no-prealloc", action="store_true", help="let the operators grow their pinned arenas inside the timed region (round-1 behaviour)")
     ap.add_argument("--context", choices=["hip", "emu", "null"], default="hip")
+    ap.add_argument("--handoff", choices=["arena", "files"], default="arena", help="how payloads travel operator -> sender and receiver -> operator: slots of a "
+                                                                                   "shared page-locked arena (gateway/shm_arena.py) or one tmpfs file per chunk")
     ap.add_argument("--dedup-wire", action="store_true", help="dedup on the wire (gateway/dedup_wire.py): a 50 %%-duplicate stream, recipes instead of frames, "
                                                             "one destination worker process (its lanes share the segment store)")
     a = ap.parse_args()
@@ -166,14 +168,14 @@ def main():
         main_reqs = [make(K + i) for i in range(a.chunks)]
         shares = [[warm[k]] + main_reqs[k::K] for k in range(K)]
         port_q, done_q = Queue(), Queue()
-        rx = Process(target=receiver_main, args=(dst, port_q, done_q, K))
+        rx = Process(target=receiver_main, args=(dst, port_q, done_q, K, (2 * a.max_batch * max(a.workers, 1) + K) if a.handoff == "arena" else 0, size))
         rx.start()
         port = port_q.get(timeout=120)
         err_ev, err_q = Event(), Queue()
         kw = {"context_factory": factory} if factory else {}
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
-                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, **kw)
+                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if a.dedup_wire else a.workers,
                                    max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], **kw)
         total = K + a.chunks
@@ -217,7 +219,7 @@ def main():
                         return
                     dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
                     dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
-                    n_sent = hip_sender.send_chunk(sock, src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1)
+                    n_sent = hip_sender.send_chunk(sock, src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1, release=True)
                     if idx:
                         wire[k] += n_sent
                     trace["sent"].append(time.perf_counter())
@@ -273,7 +275,7 @@ def main():
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "dedup_wire": a.dedup_wire, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null"}))
 

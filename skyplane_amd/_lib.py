@@ -13,7 +13,7 @@ EXPORTS = (
     "skyhip_abi_version", "skyhip_create", "skyhip_destroy", "skyhip_frame_bound", "skyhip_process_batch", "skyhip_process_device",
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
-    "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault",
+    "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault", "skyhip_host_register", "skyhip_host_unregister",
 )
 
 
@@ -63,6 +63,10 @@ def load() -> C.CDLL:
     lib.skyhip_host_alloc.restype = C.c_int
     lib.skyhip_host_free.argtypes = [vp, vp]
     lib.skyhip_host_free.restype = C.c_int
+    lib.skyhip_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.skyhip_host_register.restype = C.c_int
+    lib.skyhip_host_unregister.argtypes = [vp, vp]
+    lib.skyhip_host_unregister.restype = C.c_int
     lib.skyhip_process_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
     lib.skyhip_process_batch.restype = C.c_int
     lib.skyhip_process_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]

@@ -169,6 +169,7 @@ struct skyhip_ctx {
     hipStream_t s_up = nullptr, s_down = nullptr;
     std::vector<hipEvent_t> ev_up;    // upload-complete event per LZ4 sub-batch of a group (grow-only)
     std::vector<void*> host_allocs;   // skyhip_host_alloc'ed blocks still alive (freed by skyhip_destroy at the latest)
+    std::vector<void*> host_regs;     // skyhip_host_register'ed ranges of the caller (unregistered by skyhip_destroy at the latest)
 #ifdef SKY_WITH_CDC
     SkyCdcState cdc;   // CDC / dedup state
 #endif
@@ -355,6 +356,8 @@ void skyhip_destroy(skyhip_ctx* c) {
     c->ev_up.clear();
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     c->host_allocs.clear();
+    for (void* p : c->host_regs) (void)hipHostUnregister(p);
+    c->host_regs.clear();
     c->dec.release();
 #ifdef SKY_WITH_CDC
     sky_cdc_state_release(&c->cdc);
@@ -572,6 +575,30 @@ int skyhip_host_free(skyhip_ctx* c, void* p) {
             HIPCHK(c, hipStreamSynchronize(c->s_up));      // no copy of ours may still be reading / writing it
             HIPCHK(c, hipStreamSynchronize(c->s_down));
             HIPCHK(c, hipHostFree(p));
+            return SKYHIP_OK;
+        }
+    }
+    return SKYHIP_E_INVAL;   // not one of ours
+}
+
+int skyhip_host_register(skyhip_ctx* c, void* p, size_t bytes) {
+    if (!c || !p || bytes == 0) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    c->host_regs.push_back(p);
+    return SKYHIP_OK;
+}
+
+int skyhip_host_unregister(skyhip_ctx* c, void* p) {
+    if (!c) return SKYHIP_E_INVAL;
+    if (!p) return SKYHIP_OK;
+    for (size_t i = 0; i < c->host_regs.size(); i++) {
+        if (c->host_regs[i] == p) {
+            c->host_regs.erase(c->host_regs.begin() + (long)i);
+            HIPCHK(c, hipSetDevice(c->dev));
+            HIPCHK(c, hipStreamSynchronize(c->s_up));      // no copy of ours may still be reading / writing it
+            HIPCHK(c, hipStreamSynchronize(c->s_down));
+            HIPCHK(c, hipHostUnregister(p));
             return SKYHIP_OK;
         }
     }

@@ -18,7 +18,8 @@ class ChunkStore:
     def __init__(self, chunk_dir: PathLike):
         self.chunk_dir = Path(chunk_dir)
         self.chunk_dir.mkdir(parents=True, exist_ok=True)
-        for f in list(self.chunk_dir.glob("*.chunk")) + list(self.chunk_dir.glob("*.chunk" + SIDECAR_SUFFIX)) + list(self.chunk_dir.glob("*.chunk" + DIGEST_SUFFIX)):
+        for f in (list(self.chunk_dir.glob("*.chunk")) + list(self.chunk_dir.glob("*.chunk" + SIDECAR_SUFFIX)) + list(self.chunk_dir.glob("*.chunk" + DIGEST_SUFFIX)) +
+                  list(self.chunk_dir.glob("_arena_*.shm"))):      # (arenas of the shared-memory hand-off left by a crashed run)
             f.unlink()
         self.chunk_requests: Dict[str, GatewayQueue] = {}
         self.chunk_status_queue: Queue = Queue()

@@ -32,7 +32,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from skyplane_amd.chunk import ChunkRequest, ChunkState
-from skyplane_amd.gateway import dedup_wire, sidecar
+from skyplane_amd.gateway import dedup_wire, shm_arena, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
 
@@ -139,8 +139,15 @@ class GatewayHipCompress(GatewayOperator):
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004,
-                 prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 8 << 30):
+                 prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
+        # How a frame reaches the sender.  "arena": the device writes it by DMA into a slot of a shared, page-locked arena file in
+        # the chunk directory and `<id>.chunk.lz4f` is a pointer to the slot (gateway/shm_arena.py) -- the sender sendfile()s it from there and unlinks
+        # the pointer, which frees the slot.  "files": one payload file per chunk, as in rounds 1-2 (also what a chunk falls back to when every slot
+        # is still waiting for its sender).  `arena_slots` per lane (0 = 2 x max_batch).
+        assert handoff in ("arena", "files")
+        self.handoff = handoff
+        self.arena_slots = int(arena_slots)
         # dedup on the wire (skyplane_amd/gateway/dedup_wire.py): every chunk leaves as a recipe -- literal segments, LZ4-compressed, plus references to
         # segments this lane sent before -- instead of as one LZ4 frame.  Needs gpu_decompress(dedup_wire=True) on the destination gateway.
         self.dedup_wire = bool(dedup_wire)
@@ -216,6 +223,17 @@ class GatewayHipCompress(GatewayOperator):
             self._arenas[which] = cur
         return cur
 
+    def _writer(self, ctx) -> "shm_arena.ArenaWriter":
+        """This lane's arena (created on first use, page-locked through the lane's context when that is a real device)."""
+        w = getattr(self._tls, "writer", None)
+        if w is None:
+            bound = ctx.frame_bound(self.max_chunk_bytes) if hasattr(ctx, "frame_bound") else 15 + self.max_chunk_bytes + 4 * ((self.max_chunk_bytes + 65535) // 65536) + 4
+            tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
+            w = shm_arena.ArenaWriter(self.chunk_store.get_chunk_file_path("x").parent, tag, bound, self.arena_slots or 2 * self.max_batch)
+            shm_arena.register_once(w.arena, ctx)
+            self._tls.writer = w
+        return w
+
     def _read_chunks(self, chunk_reqs: List[ChunkRequest], ctx):
         """Raw bytes of every request.  With a real context: views of the pinned arena filled by readinto (zero-copy
         hand-off); otherwise plain bytes, as the reference reads them at gateway_operator.py:350-351."""
@@ -248,25 +266,39 @@ class GatewayHipCompress(GatewayOperator):
     def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
         ctx = self._context()
         datas = self._read_chunks(chunk_reqs, ctx)
-        if hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound"):
-            bounds = [ctx.frame_bound(len(d)) for d in datas]
-            out = self._arena(ctx, "out", sum((b + 255) & ~255 for b in bounds))
-            views, pos = [], 0
-            for b in bounds:
-                views.append(out[pos:pos + b])
-                pos += (b + 255) & ~255
-            results = ctx.process_batch(datas, flags=self._flags(), frames_into=views)
-        else:
-            results = ctx.process_batch(datas, flags=self._flags())
+        # frames that go out as they are (no recipes) are produced straight into arena slots when there are free ones
+        writer = self._writer(ctx) if (self.handoff == "arena" and not self.dedup_wire) else None
+        slots = writer.take(len(datas)) if writer is not None else []
+        try:
+            if hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound"):
+                bounds = [ctx.frame_bound(len(d)) for d in datas]
+                rest = bounds[len(slots):]
+                out = self._arena(ctx, "out", sum((b + 255) & ~255 for b in rest)) if rest else None
+                views, pos = [writer.arena.slot(s)[:b] for s, b in zip(slots, bounds)], 0
+                for b in rest:
+                    views.append(out[pos:pos + b])
+                    pos += (b + 255) & ~255
+                results = ctx.process_batch(datas, flags=self._flags(), frames_into=views)
+            else:
+                results = ctx.process_batch(datas, flags=self._flags())
+                for s, res in zip(slots, results):                # a context without DMA targets (emulator): one copy into the slot
+                    writer.arena.slot(s)[:len(res.frame)] = np.frombuffer(res.frame, np.uint8)
+        except BaseException:
+            for s in slots:
+                writer.give_back(s)
+            raise
         recipes = self._build_recipes(ctx, datas, results) if self.dedup_wire else None
         self._last_metadata = []
         for k, (cr, data, res) in enumerate(zip(chunk_reqs, datas, results)):
             cid = cr.chunk.chunk_id
             payload = recipes[k][0] if recipes is not None else res.frame
-            tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
-            with open(tmp, "wb") as f:
-                f.write(payload)
-            os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
+            if k < len(slots):
+                writer.publish(slots[k], sidecar.compressed_path(self.chunk_store, cid), len(payload))      # pointer file: complete when visible
+            else:
+                tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
+                with open(tmp, "wb") as f:
+                    f.write(payload)
+                os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
             meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": len(data)}
             if recipes is not None:
                 meta["dedup_reference_bytes"] = recipes[k][1]
@@ -331,8 +363,16 @@ class GatewayHipCompress(GatewayOperator):
         if not (hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound")):
             return
         per = (ctx.frame_bound(self.max_chunk_bytes) + 255) & ~255
+        # with the shared-memory hand-off the payload side needs no private staging: the compressor's frames go to its arena (made and page-locked
+        # here), the decompressor's payloads come from the receiver's
+        decomp = isinstance(self, GatewayHipDecompress)
+        arena_side = "in" if decomp else "out"
         for which in ("in", "out"):
+            if self.handoff == "arena" and not self.dedup_wire and which == arena_side:
+                continue
             self._arena(ctx, which, per * self.max_batch)[::4096] = 0
+        if self.handoff == "arena" and not self.dedup_wire and not decomp:
+            self._writer(ctx)
 
     def _lane_loop(self, worker_id: int):
         """One pipeline lane: drain up to max_batch requests, one device call, hand the chunks on."""
@@ -382,6 +422,12 @@ class GatewayHipCompress(GatewayOperator):
             t.join()
 
     def worker_exit(self, worker_id: int):
+        w = getattr(self._tls, "writer", None)
+        if w is not None:
+            self._tls.writer = None
+            shm_arena.forget(w.arena)
+            # (the file stays while a pointer into it may still be waiting for its sender; the chunk directory is wiped at daemon start)
+            w.arena.close(unlink=not any(o is not None and o.exists() for o in w._owner))
         if self._ctx is not None:
             self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
@@ -508,29 +554,36 @@ class GatewayHipDecompress(GatewayHipCompress):
             return oks
         pinned = hasattr(ctx, "pinned_buffer")
         paths = [sidecar.compressed_path(self.chunk_store, chunk_reqs[i].chunk.chunk_id) for i in todo]
-        sizes = [p.stat().st_size for p in paths]
+        # a payload is a file, or a pointer to a slot of the receiver's shared arena (gateway/shm_arena.py): the latter is uploaded from where the
+        # socket's bytes landed -- the arena is page-locked for this process on first sight -- instead of being read into a staging buffer first
+        opened = [shm_arena.open_payload(p) for p in paths]
+        sizes = [pl.length for pl in opened]
         chunk_lens = [int(chunk_reqs[i].chunk.chunk_length_bytes) for i in todo]
         payloads, into = [], None
         if pinned:
-            arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
+            arena = self._arena(ctx, "in", sum((pl.length + 255) & ~255 for pl in opened if pl.arena is None) or 1)
             out = self._arena(ctx, "out", sum((max(r, 1) + 255) & ~255 for r in chunk_lens))
             into, pi, po = [], 0, 0
-            for p, s, r in zip(paths, sizes, chunk_lens):
-                v = arena[pi:pi + s]
-                with open(p, "rb") as f:
-                    got, mv = 0, memoryview(v)
-                    while got < s:
-                        k = f.readinto(mv[got:])
-                        if not k:
-                            break
-                        got += k
-                assert got == s, f"payload {p.name} shrank while being read"
-                payloads.append(v)
+            for p, pl, s, r in zip(paths, opened, sizes, chunk_lens):
+                if pl.arena is not None:
+                    shm_arena.register_once(pl.arena, ctx)
+                    payloads.append(pl.view)
+                else:
+                    v = arena[pi:pi + s]
+                    with open(p, "rb") as f:
+                        got, mv = 0, memoryview(v)
+                        while got < s:
+                            k = f.readinto(mv[got:])
+                            if not k:
+                                break
+                            got += k
+                    assert got == s, f"payload {p.name} shrank while being read"
+                    payloads.append(v)
+                    pi += (s + 255) & ~255
                 into.append(out[po:po + max(r, 1)])
-                pi += (s + 255) & ~255
                 po += (max(r, 1) + 255) & ~255
         else:
-            payloads = [p.read_bytes() for p in paths]
+            payloads = [pl.view if pl.arena is not None else p.read_bytes() for p, pl in zip(paths, opened)]
         # a payload is an LZ4 frame of the chunk, or a recipe whose literal stream is one (dedup_wire.py): one batched decode for both kinds
         recipes = [None] * len(todo)
         frames, raw_lens = list(payloads), list(chunk_lens)

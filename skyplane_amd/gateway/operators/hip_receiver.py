@@ -13,7 +13,7 @@ import socket
 from typing import Callable, List, Optional
 
 from skyplane_amd.chunk import WireProtocolHeader
-from skyplane_amd.gateway import sidecar
+from skyplane_amd.gateway import shm_arena, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 
 MB = 1024 * 1024
@@ -24,8 +24,15 @@ def frame_bound(raw_len: int) -> int:
     return 15 + raw_len + 4 * ((raw_len + 65535) // 65536) + 4
 
 
+def make_arena(chunk_store: ChunkStore, tag: str, max_chunk_bytes: int, n_slots: int) -> "shm_arena.ArenaWriter":
+    """The receiver's side of the shared-memory hand-off (gateway/shm_arena.py): one arena per receiver process, shared by its connections; slots
+    hold one wire payload each (a frame or a dedup recipe of a chunk of at most max_chunk_bytes)."""
+    slot = frame_bound(max_chunk_bytes) + 33 + 21 * (max_chunk_bytes // 1024 + 2)
+    return shm_arena.ArenaWriter(chunk_store.get_chunk_file_path("x").parent, f"rx_{tag}_{os.getpid()}", slot, n_slots)
+
+
 def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Optional[Callable[[bytes, int], bytes]], recv_block_size: int = 4 * MB,
-                max_chunk_bytes: int = 1024 * MB) -> List[str]:
+                max_chunk_bytes: int = 1024 * MB, arena: Optional["shm_arena.ArenaWriter"] = None) -> List[str]:
     """`decompress(frame, raw_len)` stands where lz4.frame.decompress stands in the reference, e.g.
     ``lambda f, n: ctx.decompress_batch([f], [n])[0]`` with a SkyHipContext.
     ``decompress=None`` defers the decode to the batching ``gpu_decompress`` operator (GatewayHipDecompress): a
@@ -39,8 +46,27 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
         if header.raw_data_len > max_chunk_bytes or header.data_len > frame_bound(max_chunk_bytes) + 33 + 21 * (max_chunk_bytes // 1024 + 2):
             raise ValueError(f"[Gateway] chunk {header.chunk_id}: header announces {header.data_len} wire / {header.raw_data_len} raw bytes, limit {max_chunk_bytes}")
         if header.is_compressed and decompress is None:
-            # deferred decode: stream the payload to its sidecar in recv_block_size pieces, never holding it whole
             final = sidecar.compressed_path(chunk_store, header.chunk_id)
+            slots = arena.take(1) if (arena is not None and 0 < header.data_len <= arena.arena.slot_bytes) else []
+            if slots:
+                # shared-memory hand-off: the socket's bytes land in a slot of the arena gpu_decompress uploads from (page-locked there); what the
+                # chunk directory gets is a pointer file, and gpu_decompress unlinking it frees the slot
+                try:
+                    view, got = memoryview(arena.arena.slot(slots[0])), 0
+                    while got < header.data_len:
+                        n = conn.recv_into(view[got:header.data_len], min(header.data_len - got, recv_block_size))
+                        if n == 0:
+                            raise ConnectionError(f"socket closed after {got} of {header.data_len} bytes of chunk {header.chunk_id}")
+                        got += n
+                except BaseException:
+                    arena.give_back(slots[0])
+                    raise
+                arena.publish(slots[0], final, header.data_len)
+                received.append(header.chunk_id)
+                if header.n_chunks_left_on_socket == 0:
+                    return received
+                continue
+            # deferred decode through a file: stream the payload to its sidecar in recv_block_size pieces, never holding it whole
             tmp = final.with_suffix(".rxtmp")
             got = 0
             with open(tmp, "w+b") as f:

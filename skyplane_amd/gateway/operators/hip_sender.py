@@ -9,7 +9,7 @@ import os
 from typing import Optional, Tuple
 
 from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
-from skyplane_amd.gateway import sidecar
+from skyplane_amd.gateway import shm_arena, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 
 
@@ -17,7 +17,7 @@ def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left
     chunk = chunk_req.chunk
     frame_path = sidecar.compressed_path(chunk_store, chunk.chunk_id)
     if frame_path.exists():
-        data = frame_path.read_bytes()
+        data = shm_arena.read_payload(frame_path)       # the payload file, or the arena slot a pointer file names
         header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=len(data),
                                       raw_wire_length=chunk.chunk_length_bytes, is_compressed=True)
         return header, data
@@ -27,7 +27,7 @@ def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left
     return header, data
 
 
-def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int) -> int:
+def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int, release: bool = False) -> int:
     """Header + payload of one chunk, the payload straight from its file to the socket (``socket.sendfile`` -> os.sendfile on a plain TCP
     socket): the same bytes ``wire_payload`` + ``sendall`` put on the wire without the copy through a Python ``bytes`` -- the frame was
     produced by the GPU, the CPU has no reason to touch it.  Returns the payload bytes sent.  (A TLS-wrapped socket, as the reference uses
@@ -35,7 +35,22 @@ def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_
     chunk = chunk_req.chunk
     frame_path = sidecar.compressed_path(chunk_store, chunk.chunk_id)
     compressed = frame_path.exists()
-    path = frame_path if compressed else chunk_store.get_chunk_file_path(chunk.chunk_id)
+    if compressed:
+        # the frame lives in a payload file or -- gpu_compress(handoff="arena") -- in a slot of the shared arena that `<id>.chunk.lz4f` points to:
+        # either way its pages go to the socket by sendfile; `release` unlinks the sidecar afterwards, which is what frees an arena slot
+        size = shm_arena.open_payload(frame_path).length
+        header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=size, raw_wire_length=chunk.chunk_length_bytes, is_compressed=True)
+        header.to_socket(sock)
+        sent = shm_arena.sendfile_payload(sock, frame_path)
+        if sent != size:
+            raise ConnectionError(f"chunk {chunk.chunk_id}: {sent} of {size} payload bytes sent")
+        if release:
+            try:
+                frame_path.unlink()
+            except FileNotFoundError:
+                pass
+        return size
+    path = chunk_store.get_chunk_file_path(chunk.chunk_id)
     with open(path, "rb") as f:
         size = os.fstat(f.fileno()).st_size
         if not compressed:

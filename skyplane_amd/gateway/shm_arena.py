@@ -1,0 +1,282 @@
+"""Shared-memory hand-off of wire payloads between the GPU operators and the processes on either side of them (SURVEY.md 8f item 2:
+"pinned shared memory instead of tmpfs files").
+
+The reference hands a chunk from operator to operator as ONE FILE PER CHUNK in the gateway's chunk directory (a tmpfs;
+``ChunkStore.get_chunk_file_path``, skyplane/gateway/chunk_store.py:108-109): GatewaySender re-reads it with ``f.read()``
+(gateway_operator.py:350-351), GatewayReceiver writes it with ``f.write()`` (gateway_receiver.py:204-211).  With gpu_compress upstream that
+meant: frame -> pinned staging -> ``write()`` into ``<id>.chunk.lz4f`` -> ``read()``/sendfile.  Here the frame's home is a slot of an ARENA: one
+file in the same directory, mapped MAP_SHARED by everybody who needs it and page-locked once by the process that owns a device context
+(``skyhip_host_register``), so that
+
+    source:       device --DMA--> arena slot --sendfile--> socket                        (no CPU copy of the frame)
+    destination:  socket --recv_into--> arena slot --DMA--> device                       (one copy: kernel socket buffer -> arena)
+
+What the reference's ChunkStore contract still sees is a file with the sidecar's name (``<id>.chunk.lz4f``): a 26-byte-plus-name POINTER
+(magic "SKYSHM1\\0", offset, length, arena file name) written under a temporary name and renamed, so its existence still means "the payload is
+complete", and unlinking it -- what the consumer does when it is done with the payload -- is what frees the slot.  A payload that starts with
+the LZ4 frame magic or a recipe's "SKYD" is a plain payload file as before: both forms are accepted everywhere (``open_payload``), and a
+producer that finds no free slot simply falls back to writing the file.  Nothing here touches the wire format or chunk.py."""
+from __future__ import annotations
+
+import mmap
+import os
+import struct
+import threading
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+MAGIC = b"SKYSHM1\x00"
+_PTR = struct.Struct("<8sQQH")
+_HDR = struct.Struct("<8sQQ")          # arena file header: magic, slot_bytes, n_slots (first page)
+HEADER_BYTES = 4096
+ARENA_PREFIX = "_arena_"
+ARENA_SUFFIX = ".shm"
+
+
+class ArenaError(ValueError):
+    """A pointer file or arena that is not what it claims to be."""
+
+
+class ShmArena:
+    """``n_slots`` slots of ``slot_bytes`` in one file, mapped shared.  create=True makes (and sizes) the file; otherwise it is opened."""
+
+    def __init__(self, path, slot_bytes: int = 0, n_slots: int = 0, create: bool = False):
+        self.path = Path(path)
+        if create:
+            slot_bytes = (int(slot_bytes) + 4095) & ~4095
+            assert slot_bytes > 0 and n_slots > 0
+            fd = os.open(self.path, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o600)
+            os.ftruncate(fd, HEADER_BYTES + slot_bytes * n_slots)
+            os.pwrite(fd, _HDR.pack(MAGIC, slot_bytes, n_slots), 0)
+        else:
+            fd = os.open(self.path, os.O_RDWR)
+            magic, slot_bytes, n_slots = _HDR.unpack(os.pread(fd, _HDR.size, 0))
+            if magic != MAGIC or slot_bytes <= 0 or n_slots <= 0 or os.fstat(fd).st_size < HEADER_BYTES + slot_bytes * n_slots:
+                os.close(fd)
+                raise ArenaError(f"{self.path} is not an arena file")
+        self.fd, self.slot_bytes, self.n_slots = fd, int(slot_bytes), int(n_slots)
+        self.size = HEADER_BYTES + self.slot_bytes * self.n_slots
+        self._mm = mmap.mmap(fd, self.size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+        self.buf = np.frombuffer(self._mm, np.uint8)         # the whole mapping (what skyhip_host_register page-locks)
+
+    def slot_offset(self, i: int) -> int:
+        return HEADER_BYTES + i * self.slot_bytes
+
+    def slot(self, i: int) -> np.ndarray:
+        o = self.slot_offset(i)
+        return self.buf[o:o + self.slot_bytes]
+
+    def view(self, off: int, length: int) -> np.ndarray:
+        if off < HEADER_BYTES or off + length > self.size:
+            raise ArenaError(f"range {off}+{length} lies outside arena {self.path.name}")
+        return self.buf[off:off + length]
+
+    def close(self, unlink: bool = False):
+        if unlink:
+            try:
+                self.path.unlink()
+            except FileNotFoundError:
+                pass
+        try:
+            self.buf = None
+            self._mm.close()
+        except (BufferError, ValueError):
+            pass                                               # views still alive somewhere: the mapping goes with them
+        try:
+            os.close(self.fd)
+        except OSError:
+            pass
+
+
+def write_pointer(pointer_path: Path, arena: ShmArena, off: int, length: int):
+    """<id>.chunk.lz4f := pointer to arena[off : off + length], visible only when complete (temporary name + rename)."""
+    name = arena.path.name.encode()
+    tmp = pointer_path.with_name(pointer_path.name + ".ptmp")
+    with open(tmp, "wb") as f:
+        f.write(_PTR.pack(MAGIC, off, length, len(name)) + name)
+    os.replace(tmp, pointer_path)
+
+
+def parse_pointer(blob: bytes) -> Optional[Tuple[str, int, int]]:
+    """(arena file name, offset, length) when blob is a pointer; None when it is a plain payload."""
+    if len(blob) < 8 or blob[:8] != MAGIC:
+        return None
+    if len(blob) < _PTR.size:
+        raise ArenaError("truncated pointer file")
+    _, off, length, nlen = _PTR.unpack_from(blob, 0)
+    name = blob[_PTR.size:_PTR.size + nlen].decode("utf-8", "replace")
+    if len(blob) != _PTR.size + nlen or not name.startswith(ARENA_PREFIX) or not name.endswith(ARENA_SUFFIX) or "/" in name or "\x00" in name:
+        raise ArenaError(f"malformed pointer file (arena name {name!r})")
+    return name, int(off), int(length)
+
+
+class ArenaWriter:
+    """Producer side: hands out free slots of ONE arena and publishes pointers to them.  A slot is free again when the pointer that was published
+    for it no longer exists (the consumer unlinked it) -- a stat() per candidate slot, no other IPC.  Thread-safe."""
+
+    def __init__(self, directory, tag: str, slot_bytes: int, n_slots: int):
+        self.dir = Path(directory)
+        self.arena = ShmArena(self.dir / f"{ARENA_PREFIX}{tag}{ARENA_SUFFIX}", slot_bytes, n_slots, create=True)
+        self._owner: List[Optional[Path]] = [None] * n_slots
+        self._busy = [False] * n_slots                        # taken, not yet published
+        self._next = 0
+        self._lock = threading.Lock()
+
+    def take(self, want: int) -> List[int]:
+        """Up to `want` free slots (possibly none: the caller then writes plain files)."""
+        got: List[int] = []
+        with self._lock:
+            n = self.arena.n_slots
+            for k in range(n):
+                if len(got) >= want:
+                    break
+                i = (self._next + k) % n
+                if self._busy[i]:
+                    continue
+                own = self._owner[i]
+                if own is not None and own.exists():
+                    continue
+                self._owner[i] = None
+                self._busy[i] = True
+                got.append(i)
+            if got:
+                self._next = (got[-1] + 1) % n
+        return got
+
+    def publish(self, slot: int, pointer_path: Path, length: int):
+        assert 0 <= length <= self.arena.slot_bytes
+        write_pointer(pointer_path, self.arena, self.arena.slot_offset(slot), length)
+        with self._lock:
+            self._owner[slot] = pointer_path
+            self._busy[slot] = False
+
+    def give_back(self, slot: int):
+        with self._lock:
+            self._busy[slot] = False
+
+    def close(self):
+        self.arena.close(unlink=True)
+
+
+# ---- consumer side: a per-process cache of opened arenas ----
+_open_lock = threading.Lock()
+_opened: Dict[str, ShmArena] = {}
+_registered: Dict[str, object] = {}
+
+
+def _arena_for(pointer_path: Path, name: str) -> ShmArena:
+    key = str(pointer_path.parent / name)
+    with _open_lock:
+        a = _opened.get(key)
+        if a is None:
+            a = ShmArena(key)
+            _opened[key] = a
+        return a
+
+
+def register_once(arena: ShmArena, ctx) -> bool:
+    """Page-lock the arena for this PROCESS through ctx (hipHostRegister is per process: the lanes of a worker share one registration).
+    Returns True when this call did it.  A context without register_host (emulator, null device) needs none."""
+    if not hasattr(ctx, "register_host"):
+        return False
+    key = str(arena.path)
+    with _open_lock:
+        if key in _registered:
+            return False
+        ctx.register_host(arena.buf)
+        _registered[key] = ctx
+        return True
+
+
+def forget(arena: ShmArena, ctx=None):
+    key = str(arena.path)
+    with _open_lock:
+        owner = _registered.pop(key, None)
+        _opened.pop(key, None)
+    if owner is not None and hasattr(owner, "unregister_host"):
+        try:
+            owner.unregister_host(arena.buf)
+        except Exception:
+            pass
+
+
+class Payload:
+    """What a sidecar path leads to: `view` (uint8 array over the arena, zero-copy) for a pointer, otherwise a plain file to be read."""
+
+    __slots__ = ("path", "arena", "off", "length")
+
+    def __init__(self, path: Path, arena: Optional[ShmArena], off: int, length: int):
+        self.path, self.arena, self.off, self.length = path, arena, off, length
+
+    @property
+    def view(self) -> Optional[np.ndarray]:
+        return None if self.arena is None else self.arena.view(self.off, self.length)
+
+
+def open_payload(path) -> Payload:
+    """Resolve `<id>.chunk.lz4f`: a pointer into an arena of the same directory, or the payload itself."""
+    path = Path(path)
+    with open(path, "rb") as f:
+        head = f.read(8)
+        if head != MAGIC:
+            return Payload(path, None, 0, os.fstat(f.fileno()).st_size)
+        blob = head + f.read(4096)
+    name, off, length = parse_pointer(blob)
+    arena = _arena_for(path, name)
+    arena.view(off, length)                                   # bounds check now, not at first use
+    return Payload(path, arena, off, length)
+
+
+def read_payload(path) -> bytes:
+    """The payload's bytes whichever form it has (what a sender that wants ``data = f.read()`` calls: INTEGRATION.md section 6)."""
+    p = open_payload(path)
+    if p.arena is None:
+        return Path(path).read_bytes()
+    return p.view.tobytes()
+
+
+def take_payload(path, blob: bytes) -> bytes:
+    """For a sender that has just done ``data = f.read()`` on the sidecar (the reference's GatewaySender after INTEGRATION.md section 6): `blob`
+    itself when the sidecar is the payload; the slot's bytes when it is a pointer -- the pointer is unlinked right away (the sender holds the bytes
+    now, as it does in the reference), which gives the slot back to gpu_compress.  Should the sender fail and the chunk be re-queued, it finds no
+    sidecar and takes the reference's own path (raw chunk, CPU compression): slower, never wrong."""
+    ptr = parse_pointer(blob)
+    if ptr is None:
+        return blob
+    path = Path(path)
+    arena = _arena_for(path, ptr[0])
+    data = arena.view(ptr[1], ptr[2]).tobytes()
+    try:
+        path.unlink()
+    except FileNotFoundError:
+        pass
+    return data
+
+
+def sendfile_payload(sock, path) -> int:
+    """Payload straight to a socket: arena (or file) pages -> socket buffer, no pass through Python bytes.  Returns the bytes sent."""
+    p = open_payload(path)
+    if p.arena is None:
+        with open(path, "rb") as f:
+            return sock.sendfile(f, 0, p.length) if p.length else 0
+    sent, fd_out = 0, sock.fileno()
+    if hasattr(sock, "_sslobj"):                              # TLS: no kernel path, plain sends of the view
+        sock.sendall(p.view)
+        return p.length
+    tmo = sock.gettimeout()
+    while sent < p.length:
+        try:
+            n = os.sendfile(fd_out, p.arena.fd, p.off + sent, p.length - sent)
+        except BlockingIOError:
+            if tmo == 0:
+                raise
+            import select
+
+            select.select([], [fd_out], [], tmo)
+            continue
+        if n == 0:
+            raise ConnectionError(f"socket closed after {sent} of {p.length} payload bytes")
+        sent += n
+    return sent

@@ -91,6 +91,15 @@ class SkyHipContext:
         if p is not None and self._h:
             self._check(self._lib.skyhip_host_free(self._h, C.c_void_p(p)))
 
+    def register_host(self, buf: np.ndarray):
+        """Page-lock memory the caller owns (a MAP_SHARED mapping of an arena file: gateway/shm_arena.py) so that copies to and from it are
+        asynchronous DMA like those of a pinned_buffer.  Once per arena, not per chunk."""
+        self._check(self._lib.skyhip_host_register(self._h, C.c_void_p(buf.ctypes.data), int(buf.nbytes)))
+
+    def unregister_host(self, buf: np.ndarray):
+        if self._h:
+            self._check(self._lib.skyhip_host_unregister(self._h, C.c_void_p(buf.ctypes.data)))
+
     # -- host-buffer path (what the gateway operator uses) -------------------------------------------
     def process_batch(self, chunks: Sequence, flags: int = F_LZ4 | F_MD5, frames_into: Optional[Sequence[np.ndarray]] = None) -> List[ChunkResult]:
         """chunks: bytes-like objects or uint8 arrays (views of a pinned_buffer for the asynchronous path).

@@ -105,7 +105,10 @@ def _patched_sender_module():
         ('            with open(chunk_file_path, "rb") as f:\n                data = f.read()\n',
          '            lz4f_path = chunk_file_path.with_name(chunk_file_path.name + ".lz4f")\n'
          '            precompressed = lz4f_path.exists()                      # produced by gpu_compress\n'
-         '            with open(lz4f_path if precompressed else chunk_file_path, "rb") as f:\n                data = f.read()\n'),
+         '            with open(lz4f_path if precompressed else chunk_file_path, "rb") as f:\n                data = f.read()\n'
+         '            if precompressed:                                       # a frame, or a pointer into gpu_compress\'s shared arena\n'
+         '                from skyplane_amd.gateway.shm_arena import take_payload\n'
+         '                data = take_payload(lz4f_path, data)\n'),
         ('            assert len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size',
          '            assert precompressed or len(data) == chunk.chunk_length_bytes, f"chunk {chunk_id} has size'),
         ('            raw_wire_length = wire_length\n',
@@ -204,9 +207,16 @@ def main():
     sender.destination_ports["127.0.0.1"] = port
     sender.destination_sockets["127.0.0.1"] = sock
     wire = 0
+    from skyplane_amd.gateway import shm_arena
+
+    n_slots_used = 0
     for cr in reqs:
+        pl = shm_arena.open_payload(sidecar.compressed_path(src, cr.chunk.chunk_id))       # a payload file, or a pointer into gpu_compress's shared arena
+        n_slots_used += pl.arena is not None
+        wire += pl.length
         assert sender.process(cr, "127.0.0.1") is True
-        wire += sidecar.compressed_path(src, cr.chunk.chunk_id).stat().st_size
+        assert (pl.arena is None) == sidecar.compressed_path(src, cr.chunk.chunk_id).exists()   # take_payload released the slot (section 6)
+    assert n_slots_used > 0, "gpu_compress's default hand-off is the shared arena"
     last = dst.get_chunk_file_path(reqs[-1].chunk.chunk_id)
     t0 = time.time()
     while time.time() - t0 < 60 and not (last.exists() and last.stat().st_size == len(datas[reqs[-1].chunk.chunk_id])):
@@ -262,8 +272,15 @@ def main():
     sock2 = socket.create_connection(("127.0.0.1", port2))
     sender.destination_ports["127.0.0.1"] = port2
     sender.destination_sockets["127.0.0.1"] = sock2
+    # the arena slots of part 2 went back to gpu_compress when the sender took their frames: make the payloads again, this time with the one-file-per-chunk
+    # hand-off (handoff="files"), so that the patched reference sender is run over both forms
+    op_files = GatewayHipCompress("gpu_compress_0", "local:src", q_in, q_out, err_ev, err_q, src, n_processes=1, max_batch=4, device_ids=[0],
+                                  context_factory=lambda d, mc, mb: EmuContext(d, mc, mb), handoff="files")
+    op_files.worker_id = 0
+    assert all(op_files.process_batch(reqs))
     for cr in reqs:
-        assert sender.process(cr, "127.0.0.1") is True          # the patched reference sender again, same frames
+        assert shm_arena.open_payload(sidecar.compressed_path(src, cr.chunk.chunk_id)).arena is None
+        assert sender.process(cr, "127.0.0.1") is True          # the patched reference sender again, payload files this time
     done2, t0 = [], time.time()
     while len(done2) < len(reqs) and time.time() - t0 < 120 and not d_err_ev.is_set():
         try:
@@ -395,7 +412,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        import os
+        import traceback
+
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)          # forked reference servers would otherwise keep a failed run alive until the caller's timeout
     # the reference's logger and the drain threads above are daemon threads that may hold stderr's lock at interpreter shutdown ("could not acquire
     # lock for <stderr> at interpreter shutdown" = exit code -6 after a successful run): everything is verified and printed, leave without the teardown
     sys.stdout.flush()

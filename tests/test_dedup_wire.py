@@ -14,7 +14,7 @@ import pytest
 from oracle import ref
 from skyplane_amd import synth
 from skyplane_amd.chunk import Chunk, ChunkRequest
-from skyplane_amd.gateway import dedup_wire, gateway_program, sidecar
+from skyplane_amd.gateway import dedup_wire, gateway_program, shm_arena, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
 from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress, GatewayHipDecompress
@@ -84,7 +84,7 @@ def _ops(src, dst, ctx_src, ctx_dst, **kw):
 def _ship(src, dst, reqs):
     """What sender + deferred receiver do: the payload sidecar of every chunk appears on the destination (is_compressed payload, unchanged bytes)."""
     for cr in reqs:
-        sidecar.compressed_path(dst, cr.chunk.chunk_id).write_bytes(sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes())
+        sidecar.compressed_path(dst, cr.chunk.chunk_id).write_bytes(shm_arena.read_payload(sidecar.compressed_path(src, cr.chunk.chunk_id)))      # (a file or an arena slot)
 
 
 def _dup_chunks(n=6, size=1 << 20):
@@ -327,7 +327,7 @@ def test_staging_branches_with_plain_frames_recipes_and_both_in_one_batch(tmp_pa
                                max_chunk_bytes=4 << 20, device_ids=[0], context_factory=lambda d, mc, mb: ArenaEmuDedupContext())
     assert all(plain.process_batch(reqs[:2]))            # two chunks as plain frames ...
     assert all(comp.process_batch(reqs[2:]))             # ... four as recipes
-    kinds = [dedup_wire.is_recipe(sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes()) for cr in reqs]
+    kinds = [dedup_wire.is_recipe(shm_arena.read_payload(sidecar.compressed_path(src, cr.chunk.chunk_id))) for cr in reqs]
     assert kinds == [False, False, True, True, True, True]
     _ship(src, dst, reqs)
     assert all(dec.process_batch(reqs[:1]))              # plain only

@@ -167,7 +167,7 @@ def test_operator_zero_copy_staging_path(tmp_path, monkeypatch):
     store, q_in, q_out, reqs = _make_store(tmp_path, 7, size=70_001)         # odd size: views are 256-byte aligned, lengths are not
     err_ev, err_q = Event(), Queue()
     op = GatewayHipCompress("gpu_compress_0", "local:test", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=3, device_ids=[0],
-                            context_factory=_arena_factory)
+                            context_factory=_arena_factory, handoff="files")
     op.worker_id = 0
     crs = [cr for cr, _ in reqs]
     assert op.process_batch(crs[:2]) == [True, True]
@@ -186,6 +186,60 @@ def test_operator_zero_copy_staging_path(tmp_path, monkeypatch):
         store.get_chunk_file_path(crs[0].chunk.chunk_id).write_bytes(bad)
         with pytest.raises(AssertionError, match="should be 70001"):
             op.process_batch(crs[:1])
+    op.worker_exit(0)
+
+
+def test_operator_shared_arena_handoff(tmp_path, monkeypatch):
+    """SURVEY 8f item 2, "pinned shared memory instead of tmpfs files": with handoff="arena" (the default) a frame is produced straight into a slot of
+    one shared arena file in the chunk directory; `<id>.chunk.lz4f` is a pointer to the slot; the cooperating sender sendfile()s the slot and unlinks
+    the pointer, which frees the slot; when every slot is still waiting for its sender the operator falls back to one payload file per chunk."""
+    import socket
+    from skyplane_amd.gateway import shm_arena
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    store, q_in, q_out, reqs = _make_store(tmp_path, 8, size=70_001)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "local:test", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=3, device_ids=[0],
+                            context_factory=_arena_factory, arena_slots=5)
+    op.worker_id = 0
+    crs = [cr for cr, _ in reqs]
+    assert op.process_batch(crs[:3]) == [True] * 3 and op.process_batch(crs[3:6]) == [True] * 3
+    arenas = list((tmp_path / "chunks").glob("_arena_*.shm"))
+    assert len(arenas) == 1                                                      # one arena per lane, not one file per chunk
+    kinds = []
+    for cr, data in reqs[:6]:
+        p = store.get_compressed_file_path(cr.chunk.chunk_id)
+        pl = shm_arena.open_payload(p)
+        kinds.append(pl.arena is not None)
+        if pl.arena is not None:
+            assert p.stat().st_size < 200 and pl.arena.path == arenas[0]         # a pointer, not the frame
+        assert ref.lz4f_decompress(shm_arena.read_payload(p), len(data)) == data
+        hdr, payload = hip_sender.wire_payload(store, cr, n_chunks_left_on_socket=0)
+        assert hdr.is_compressed and hdr.data_len == len(payload) and ref.lz4f_decompress(payload, len(data)) == data
+    assert kinds == [True] * 5 + [False]                                         # five slots, the sixth chunk fell back to a payload file
+    # the sender: slot pages -> socket; release=True unlinks the pointer and the slot can be taken again
+    a, b = socket.socketpair()
+    got = bytearray()
+    import threading
+    rd = threading.Thread(target=lambda: [got.extend(x) for x in iter(lambda: b.recv(1 << 16), b"")])
+    rd.start()
+    sent = hip_sender.send_chunk(a, store, crs[0], n_chunks_left_on_socket=0, release=True)
+    a.close(); rd.join(); b.close()
+    h = WireProtocolHeader.from_bytes(bytes(got[:53]))
+    assert h.is_compressed and h.data_len == sent == len(got) - 53 and ref.lz4f_decompress(bytes(got[53:]), 70_001) == reqs[0][1]
+    assert not store.get_compressed_file_path(crs[0].chunk.chunk_id).exists()
+    assert op.process_batch(crs[6:8]) == [True] * 2
+    k2 = [shm_arena.open_payload(store.get_compressed_file_path(cr.chunk.chunk_id)).arena is not None for cr in crs[6:8]]
+    assert k2 == [True, False]                                                   # exactly the one freed slot was reused
+    # untrusted pointer files: wrong arena name, range outside the arena
+    bad = tmp_path / "chunks" / "bad.chunk.lz4f"
+    bad.write_bytes(shm_arena._PTR.pack(shm_arena.MAGIC, 4096, 10, 11) + b"../../passwd")
+    with pytest.raises(shm_arena.ArenaError):
+        shm_arena.open_payload(bad)
+    name = arenas[0].name.encode()
+    bad.write_bytes(shm_arena._PTR.pack(shm_arena.MAGIC, 1 << 40, 10, len(name)) + name)
+    with pytest.raises(shm_arena.ArenaError):
+        shm_arena.open_payload(bad)
     op.worker_exit(0)
 
 
