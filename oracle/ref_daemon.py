@@ -66,6 +66,12 @@ SENDER_EDITS = [
      '            elif self.use_compression:\n                data = lz4.frame.compress(data)\n'),
 ]
 
+IDLE_EDITS = [    # INTEGRATION.md section 11 (a harness accommodation, not part of the drop-in): GatewayOperator.worker_loop busy-spins on an empty queue
+    # (gateway_operator.py:84-88); with 128 connections that is ~400 spinning processes, and the GPU box's container may use 16 CPUs.  One line.
+    ('                except queue.Empty:\n                    continue\n',
+     '                except queue.Empty:\n                    time.sleep(IDLE_SLEEP_S)                # was: (nothing) -- a busy spin\n                    continue\n'),
+]
+
 DAEMON_EDITS = [   # one more branch in create_gateway_operators
     ('                elif op["op_type"] == "write_local":\n',
      '                elif op["op_type"] == "gpu_compress":\n'
@@ -73,7 +79,8 @@ DAEMON_EDITS = [   # one more branch in create_gateway
      '                        handle=handle, region=self.region, input_queue=input_queue, output_queue=output_queue,\n'
      '                        error_event=self.error_event, error_queue=self.error_queue, chunk_store=self.chunk_store,\n'
      '                        n_processes=op["num_workers"], max_batch=op["max_batch"], max_chunk_bytes=op["max_chunk_mb"] * 1024 * 1024,\n'
-     '                        compute_md5=op["compute_md5"], cdc=op["cdc"], dedup=op["dedup"], context_factory=GPU_CONTEXT_FACTORY)\n'
+     '                        compute_md5=op["compute_md5"], cdc=op["cdc"], dedup=op["dedup"], context_factory=GPU_CONTEXT_FACTORY,\n'
+     '                        handoff=op.get("handoff", "arena"))\n'
      '                    total_p += op["num_workers"]\n'
      '                elif op["op_type"] == "write_local":\n'),
 ]
@@ -94,11 +101,30 @@ def _emu_context_factory(device_id, max_chunk_bytes, max_batch):
     return EmuContext()
 
 
-def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, log, context="emu"):
+def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, log, context="emu", idle_sleep=0.0):
     """Child process: one reference GatewayDaemon."""
     fd = os.open(log, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     os.dup2(fd, 1)
     os.dup2(fd, 2)
+    # Fork safety of the log plumbing.  The daemon forks its receiver servers and operator workers from a process that has other threads printing
+    # (the API thread forks on POST /servers while the main loop prints chunk states): a child that inherits sys.stdout's buffer lock, or rich's
+    # console lock, in the locked state blocks for ever at its first print()/logger call -- a receiver server then accepts its connection and never
+    # reads it, and that connection's chunks are "sent" and never arrive (seen here: 15 of 16 chunks, about one run in eight).  Unbuffered text
+    # streams have no lock to inherit; rich's lock is replaced in every child.
+    import io
+
+    sys.stdout = io.TextIOWrapper(io.FileIO(1, "w", closefd=False), write_through=True, errors="replace")
+    sys.stderr = io.TextIOWrapper(io.FileIO(2, "w", closefd=False), write_through=True, errors="replace")
+
+    def _fresh_locks():
+        try:
+            import rich
+
+            rich.get_console()._lock = threading.RLock()
+        except Exception:  # noqa: BLE001
+            pass
+
+    os.register_at_fork(after_in_child=_fresh_locks)
     refshim.install(Path(work) / f"shim_{role}")
     (Path(work) / f"{role}_program.json").write_text(json.dumps(program))
     (Path(work) / f"{role}_info.json").write_text(json.dumps(info))
@@ -107,6 +133,14 @@ def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, 
     import skyplane.gateway.gateway_daemon_api as api_mod
 
     api_mod.GatewayDaemonAPI.__init__.__defaults__ = ("127.0.0.1", api_port)     # host, port (two daemons on one machine)
+    edits = (SENDER_EDITS if gpu_op else []) + (IDLE_EDITS if idle_sleep > 0 else [])
+    if edits:        # the reference's operator module, patched in memory (sender cooperation for gpu_compress; the idle back-off of --idle-sleep)
+        op_path = refshim.REFERENCE / "skyplane" / "gateway" / "operators" / "gateway_operator.py"
+        op_mod = types.ModuleType("skyplane.gateway.operators.gateway_operator")
+        op_mod.__file__ = str(op_path)
+        op_mod.IDLE_SLEEP_S = idle_sleep
+        exec(compile(_apply(op_path.read_text(), edits, "operator patches"), str(op_path), "exec"), op_mod.__dict__)
+        sys.modules["skyplane.gateway.operators.gateway_operator"] = op_mod
     if gpu_op:
         import skyplane.chunk as ref_chunk
         import skyplane.gateway.chunk_store as ref_chunk_store
@@ -117,15 +151,10 @@ def daemon_main(role, region, chunk_dir, program, info, api_port, work, gpu_op, 
         sys.modules["skyplane_amd.gateway.gateway_queue"] = ref_queue
         from skyplane_amd.gateway.operators.gateway_operator import GatewayHipCompress
 
-        op_path = refshim.REFERENCE / "skyplane" / "gateway" / "operators" / "gateway_operator.py"
-        op_mod = types.ModuleType("skyplane.gateway.operators.gateway_operator")
-        op_mod.__file__ = str(op_path)
-        exec(compile(_apply(op_path.read_text(), SENDER_EDITS, "sender patch"), str(op_path), "exec"), op_mod.__dict__)
         def _no_cpu_compress(data, **kw):          # every chunk has a frame from gpu_compress: the CPU codec must stay idle
             raise AssertionError("the sender compressed on the CPU although gpu_compress had left a frame")
 
         op_mod.lz4 = types.SimpleNamespace(frame=types.SimpleNamespace(compress=_no_cpu_compress))
-        sys.modules["skyplane.gateway.operators.gateway_operator"] = op_mod
         d_path = refshim.REFERENCE / "skyplane" / "gateway" / "gateway_daemon.py"
         d_mod = types.ModuleType("skyplane.gateway.gateway_daemon")
         d_mod.__file__ = str(d_path)
@@ -229,8 +258,13 @@ def main():
     ap.add_argument("--max-batch", type=int, default=8)
     ap.add_argument("--stream", choices=["silesia", "random"], default="silesia", help="random = BASELINE configs[0]'s PRNG bytes")
     ap.add_argument("--timeout", type=int, default=600)
+    ap.add_argument("--handoff", choices=["arena", "files"], default="arena", help="gpu_compress -> sender: slots of the shared arena or one payload file per chunk")
+    ap.add_argument("--idle-sleep", type=float, default=0.0, help="seconds an idle reference operator worker sleeps instead of spinning (IDLE_EDITS; 0 = the reference as it is)")
+    ap.add_argument("--io-workers", type=int, default=0, help="workers of read_object_store / write_object_store (0 = --connections, the reference's planner default); "
+                                                             "--connections is always the sender's socket count")
     ap.add_argument("--out", default="")
     ap.add_argument("--keep-logs", action="store_true")
+    ap.add_argument("--log-dir", default="", help="copy the daemons' full logs (API access lines removed) here when the run fails")
     a = ap.parse_args()
     for port in (DST_API, DST_TLS, SRC_API):    # a daemon left over from an earlier run would silently take our requests
         with socket.socket() as probe:
@@ -264,14 +298,14 @@ def main():
             "encrypt": False, "private_ip": False, "children": []}
     if a.gpu_op:
         mid = {"op_type": "gpu_compress", "handle": "gpu", "num_workers": a.workers, "max_batch": a.max_batch, "max_chunk_mb": 64, "compute_md5": True, "cdc": False,
-               "dedup": False, "children": [send]}
+               "dedup": False, "handoff": a.handoff, "children": [send]}
     else:
         mid = send
     src_program = [{"partitions": ["0"], "value": [{"op_type": "read_object_store", "handle": "read", "bucket_name": str(src_dir), "bucket_region": "local:src",
-                                                    "num_connections": a.connections, "children": [mid]}]}]
+                                                    "num_connections": a.io_workers or a.connections, "children": [mid]}]}]
     dst_program = [{"partitions": ["0"], "value": [{"op_type": "receive", "handle": "recv", "decompress": True, "decrypt": False, "max_pending_chunks": 1000,
                                                     "children": [{"op_type": "write_object_store", "handle": "write", "bucket_name": str(dst_dir),
-                                                                  "bucket_region": "local:dst", "num_connections": a.connections, "key_prefix": "",
+                                                                  "bucket_region": "local:dst", "num_connections": a.io_workers or a.connections, "key_prefix": "",
                                                                   "children": []}]}]}]
     cert, key = work / "cert.pem", work / "key.pem"
     subprocess.run(["openssl", "req", "-x509", "-newkey", "rsa:2048", "-nodes", "-keyout", str(key), "-out", str(cert), "-days", "1", "-subj", "/CN=skyplane"],
@@ -281,12 +315,13 @@ def main():
     if a.gpu_op and a.context == "emu":
         from tests.emu import emulib
         emulib.lib()                            # build once, before the daemons fork their workers
-    procs = [Process(target=daemon_main, args=("dst", "local:dst", str(work / "dst_chunks"), dst_program, info, DST_API, str(work), False, str(work / "dst.log"))),
-             Process(target=daemon_main, args=("src", "local:src", str(work / "src_chunks"), src_program, info, SRC_API, str(work), a.gpu_op, str(work / "src.log"), a.context))]
+    procs = [Process(target=daemon_main, args=("dst", "local:dst", str(work / "dst_chunks"), dst_program, info, DST_API, str(work), False, str(work / "dst.log"), "emu", a.idle_sleep)),
+             Process(target=daemon_main, args=("src", "local:src", str(work / "src_chunks"), src_program, info, SRC_API, str(work), a.gpu_op, str(work / "src.log"), a.context, a.idle_sleep))]
     res = {"what": "two reference GatewayDaemons on localhost: read_object_store(local) -> " + ("gpu_compress -> " if a.gpu_op else "") +
                    "send(compress) -> receive -> write_object_store(local)", "chunks": a.chunks, "chunk_bytes": size, "connections": a.connections,
            "host_cores": os.cpu_count(), "schedulable_cores": len(os.sched_getaffinity(0)), "gpu_op": bool(a.gpu_op), "context": a.context if a.gpu_op else None,
-           "stream": a.stream, "gpu_workers": a.workers if a.gpu_op else None}
+           "stream": a.stream, "gpu_workers": a.workers if a.gpu_op else None, "io_workers": a.io_workers or a.connections,
+           "reference_idle_sleep_s": a.idle_sleep}
     ok = False
     try:
         for p in procs:
@@ -314,6 +349,17 @@ def main():
             # out of time: report what the DAG managed (a rate over the completed chunks) instead of nothing
             res.update({"wall_s": round(wall, 3), "gbit_s": round(done * size * 8 / wall / 1e9, 3), "gib_s": round(done * size / wall / 2**30, 4),
                         "verified": False, "timed_out": True})
+            try:      # where did the missing chunks stop?  last state per operator, from both daemons' status logs
+                fin = {e["chunk_id"] for e in log if e["state"] == "complete" and e["handle"].startswith("write_object_store")}
+                missing = [c["chunk_id"] for c in chunks if c["chunk_id"] not in fin][:4]
+                trail = {}
+                for port in (SRC_API, DST_API):
+                    for e in http_json("GET", f"http://127.0.0.1:{port}/api/v1/chunk_status_log")["chunk_status_log"]:
+                        if e["chunk_id"] in missing:
+                            trail.setdefault(e["chunk_id"], []).append(f"{port}:{e.get('handle')}:{e['state']}")
+                res["stuck"] = trail
+            except Exception as ex:  # noqa: BLE001
+                res["stuck"] = repr(ex)
             raise TimeoutError(f"{done} of {len(chunks)} chunks completed in {wall:.0f} s")
         for cid, (path, dig) in datas.items():
             assert hashlib.md5(Path(path).read_bytes()).digest() == dig, path
@@ -321,9 +367,13 @@ def main():
             prof = http_json("GET", f"http://127.0.0.1:{SRC_API}/api/v1/chunk_status_log")["chunk_status_log"]
             # (the API logs non-terminal operators' in_progress records only, gateway_daemon_api.py:147-153)
             gp = {e["chunk_id"] for e in prof if (e.get("handle") or "").startswith("gpu_compress") and e["state"] == "in_progress"}
-            assert len(gp) == len(chunks), f"gpu_compress saw {len(gp)} of {len(chunks)} chunks"
+            # (a lower bound: the API drops the records of a chunk that reach it after the chunk's terminal `complete`, gateway_daemon_api.py:107-109,
+            # and with many worker processes feeding one status queue an operator's in_progress can arrive after the sender's complete.  That every
+            # chunk went through the GPU operator is what the booby-trapped CPU compressor proves: a chunk without a frame would have raised there.)
+            assert len(gp) > 0, "gpu_compress logged nothing"
             assert "compressed on the CPU" not in (work / "src.log").read_text()
-            res["gpu_compress_chunks"] = len(gp)
+            res["gpu_compress_chunks_logged"] = len(gp)
+            res["cpu_compress_calls_in_sender"] = 0
         raw = len(chunks) * size
         res.update({"wall_s": round(wall, 3), "gbit_s": round(raw * 8 / wall / 1e9, 3), "gib_s": round(raw / wall / 2**30, 4), "verified": True})
         ok = True
@@ -333,9 +383,11 @@ def main():
             if not ok or a.keep_logs:
                 for n in ("src.log", "dst.log"):
                     if (work / n).exists():
-                        with open(work / n, "rb") as f:
-                            f.seek(max(0, (work / n).stat().st_size - 3000))
-                            sys.stderr.write(f"---- {n} (tail) ----\n" + f.read().decode("utf-8", "replace") + "\n")
+                        lines = [l for l in (work / n).read_text(errors="replace").splitlines() if "werkzeug" not in l and "/api/v1/" not in l]
+                        if a.log_dir and not ok:
+                            Path(a.log_dir).mkdir(parents=True, exist_ok=True)
+                            (Path(a.log_dir) / n).write_text("\n".join(lines) + "\n")
+                        sys.stderr.write(f"---- {n} (tail, API access lines removed) ----\n" + "\n".join(lines[-60:])[-6000:] + "\n")
             line = json.dumps(res)
             print(line, flush=True)
             if a.out and (ok or res.get("timed_out")):

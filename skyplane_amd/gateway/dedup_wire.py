@@ -21,8 +21,10 @@ from __future__ import annotations
 import fcntl
 import mmap
 import os
+import shutil
 import struct
 import threading
+import time
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
@@ -95,40 +97,92 @@ def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
     return Recipe(lane=lane, epoch=epoch, raw_len=raw_len, lit_raw_len=lit_raw, segs=segs, lit_frame=mv[HEADER_BYTES + SEG_BYTES * nseg:])
 
 
+class _Bounds:
+    """What keeps a segment store finite, shared by both stores.  (lane, epoch) groups are dropped
+      * when a newer epoch of the same lane shows up (``keep_epochs``, as before) -- checked only when a lane's highest epoch actually grows;
+      * least recently used first when the store holds more than ``max_bytes`` (the group being written is never the victim);
+      * when nothing has touched them for ``idle_s`` seconds (a transfer that ended: its lanes never send a newer epoch).
+    An epoch that jumps more than ``max_epoch_jump`` ahead of what a known lane has reached is refused: the number comes from an untrusted payload,
+    and honouring it would retire every live epoch of that lane."""
+
+    def __init__(self, keep_epochs, max_bytes, idle_s, max_epoch_jump):
+        self.keep_epochs = max(1, int(keep_epochs))
+        self.max_bytes = int(max_bytes)
+        self.idle_s = float(idle_s)
+        self.max_epoch_jump = int(max_epoch_jump)
+        self.lane_max: Dict[int, int] = {}
+        self.touched: Dict[Tuple[int, int], float] = {}
+        self.nbytes: Dict[Tuple[int, int], int] = {}
+
+    def admit(self, lane: int, epoch: int) -> List[Tuple[int, int]]:
+        """Called (under the store's lock) before (lane, epoch) is written; returns the groups to drop because of it."""
+        top = self.lane_max.get(lane)
+        if top is not None and epoch > top + self.max_epoch_jump:
+            raise RecipeError(f"lane {lane:#x} jumps from epoch {top} to {epoch}")
+        drop = []
+        if top is None or epoch > top:
+            self.lane_max[lane] = epoch
+            drop = [k for k in self.nbytes if k[0] == lane and k[1] + self.keep_epochs <= epoch]
+        now = time.monotonic()
+        self.touched[(lane, epoch)] = now
+        self.nbytes.setdefault((lane, epoch), 0)
+        if self.idle_s > 0:
+            drop += [k for k, t in self.touched.items() if now - t > self.idle_s and k not in drop and k != (lane, epoch)]
+        return drop
+
+    def over_budget(self, keep: Tuple[int, int]) -> List[Tuple[int, int]]:
+        total, drop = sum(self.nbytes.values()), []
+        for k in sorted(self.touched, key=self.touched.get):
+            if total <= self.max_bytes:
+                break
+            if k != keep:
+                drop.append(k)
+                total -= self.nbytes.get(k, 0)
+        return drop
+
+    def forget(self, key):
+        self.touched.pop(key, None)
+        self.nbytes.pop(key, None)
+        if not any(k[0] == key[0] for k in self.nbytes):
+            self.lane_max.pop(key[0], None)          # the lane is gone: a later transfer may reuse the id from any epoch
+
+
 class SegmentStore:
     """Literal segments by (lane, epoch, fingerprint), shared by the lanes (threads) of one destination worker process.  A lane's table is reset at
     every epoch change, so a reference of epoch e can only name a literal of epoch e; chunks of epoch e - 1 may still be in flight when e begins, so
-    the last ``keep_epochs`` epochs of a lane are kept and older ones dropped when a newer one shows up.  A chunk's literal stream is kept as ONE
-    bytes object and every segment as (that object, offset, length): no per-segment copies, and neighbouring segments stay neighbours, so a run of
-    references into one earlier chunk is rebuilt with one copy."""
+    the last ``keep_epochs`` epochs of a lane are kept and older ones dropped when a newer one shows up; on top of that the store is bounded in bytes
+    (LRU over (lane, epoch)) and in time (idle groups go): see _Bounds.  A chunk's literal stream is kept as ONE bytes object and every segment as
+    (that object, offset, length): no per-segment copies, and neighbouring segments stay neighbours, so a run of references into one earlier chunk
+    is rebuilt with one copy."""
 
-    def __init__(self, keep_epochs: int = 2):
+    def __init__(self, keep_epochs: int = 2, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2):
         self.keep_epochs = max(1, int(keep_epochs))
+        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump)
         self._lock = threading.Lock()
         self._segs: Dict[Tuple[int, int], Dict[bytes, Tuple[bytes, int, int]]] = {}
-        self._bytes: Dict[Tuple[int, int], int] = {}
 
     @property
     def bytes_held(self) -> int:
         with self._lock:
-            return sum(self._bytes.values())
+            return sum(self._b.nbytes.values())
 
-    def _retire(self, lane: int, epoch: int):
-        for key in [k for k in self._segs if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
-            del self._segs[key]
-            del self._bytes[key]
+    def _drop(self, keys):
+        for key in keys:
+            self._segs.pop(key, None)
+            self._b.forget(key)
 
     def put_chunk(self, lane: int, epoch: int, fps: List[bytes], offs, lens, litbuf: bytes):
         """The literal segments of one chunk: fingerprint k is litbuf[offs[k] : offs[k] + lens[k]]."""
         with self._lock:
-            self._retire(lane, epoch)
+            self._drop(self._b.admit(lane, epoch))
             d = self._segs.setdefault((lane, epoch), {})
             new = 0
             for fp, o, n in zip(fps, offs, lens):
                 if fp not in d:
                     d[fp] = (litbuf, int(o), int(n))
                     new += int(n)
-            self._bytes[(lane, epoch)] = self._bytes.get((lane, epoch), 0) + new
+            self._b.nbytes[(lane, epoch)] += new
+            self._drop(self._b.over_budget((lane, epoch)))
 
     def put_many(self, lane: int, epoch: int, fps: List[bytes], datas: List[bytes]):
         for fp, data in zip(fps, datas):
@@ -137,7 +191,13 @@ class SegmentStore:
     def get_many(self, lane: int, epoch: int, fps: List[bytes]) -> List[Optional[Tuple[bytes, int, int]]]:
         with self._lock:
             d = self._segs.get((lane, epoch), {})
+            if d:
+                self._b.touched[(lane, epoch)] = time.monotonic()
             return [d.get(fp) for fp in fps]
+
+    def cleanup(self):
+        with self._lock:
+            self._drop(list(self._segs))
 
     def get(self, lane: int, epoch: int, fp: bytes) -> Optional[bytes]:
         (hit,) = self.get_many(lane, epoch, [fp])
@@ -157,11 +217,12 @@ class FileSegmentStore:
 
     _REC = struct.Struct("<16sII16s")
 
-    def __init__(self, directory, keep_epochs: int = 2, max_maps: int = 256):
+    def __init__(self, directory, keep_epochs: int = 2, max_maps: int = 256, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2):
         self.dir = Path(directory)
         self.dir.mkdir(parents=True, exist_ok=True)
         self.keep_epochs = max(1, int(keep_epochs))
         self.max_maps = max_maps
+        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump)      # this process's view: what IT wrote or read (every worker bounds its share)
         self._lock = threading.Lock()
         self._idx: Dict[Tuple[int, int], Tuple[Dict[bytes, Tuple[bytes, int, int]], int]] = {}     # (lane, epoch) -> (fp -> (stream id, off, len), bytes of the index read)
         self._maps: Dict[bytes, mmap.mmap] = {}
@@ -172,19 +233,29 @@ class FileSegmentStore:
     def _stream_path(self, lane: int, epoch: int, sid: bytes) -> Path:
         return self.dir / f"L{lane:016x}-{epoch}-{sid.hex()}.lit"
 
-    def _retire(self, lane: int, epoch: int):
-        for key in [k for k in self._idx if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
-            del self._idx[key]
+    def _drop(self, keys):
+        """Forget (lane, epoch) groups and remove their files (index + literal streams); another worker may have been faster."""
+        for lane, epoch in keys:
+            self._idx.pop((lane, epoch), None)
+            self._b.forget((lane, epoch))
+            for p in list(self.dir.glob(f"?{lane:016x}-{epoch}-*")) + list(self.dir.glob(f"?{lane:016x}-{epoch}.*")):
+                try:
+                    p.unlink()
+                except FileNotFoundError:
+                    pass
+
+    def _retire_older(self, lane: int, epoch: int):
+        """A lane reached `epoch`: everything of that lane older than keep_epochs goes, also what OTHER workers wrote (one directory scan, done
+        only when a lane's highest epoch grows -- not per chunk)."""
+        old = set()
         for p in self.dir.glob(f"?{lane:016x}-*"):
             try:
                 e = int(p.name.split("-")[1].split(".")[0])
             except ValueError:
                 continue
             if e + self.keep_epochs <= epoch:
-                try:
-                    p.unlink()
-                except FileNotFoundError:
-                    pass                                   # another worker was faster
+                old.add((lane, e))
+        self._drop(old)
 
     def put_chunk(self, lane: int, epoch: int, fps: List[bytes], offs, lens, litbuf: bytes):
         sid = os.urandom(16)
@@ -194,7 +265,13 @@ class FileSegmentStore:
         os.replace(tmp, final)                            # a record never names a stream that is not complete
         recs = b"".join(self._REC.pack(fp, int(o), int(n), sid) for fp, o, n in zip(fps, offs, lens))
         with self._lock:
-            self._retire(lane, epoch)
+            grew = self._b.lane_max.get(lane) is None or epoch > self._b.lane_max[lane]
+            drop = self._b.admit(lane, epoch)              # (raises on an epoch far ahead of the lane: the stream file below is then an orphan of a bad payload)
+            if grew:
+                self._retire_older(lane, epoch)
+            self._drop(drop)
+            self._b.nbytes[(lane, epoch)] += len(litbuf)
+            self._drop(self._b.over_budget((lane, epoch)))
         with open(self._index_path(lane, epoch), "ab") as f:
             fcntl.flock(f, fcntl.LOCK_EX)
             f.write(recs)
@@ -218,7 +295,11 @@ class FileSegmentStore:
     def _map(self, lane: int, epoch: int, sid: bytes):
         m = self._maps.get(sid)
         if m is None:
-            with open(self._stream_path(lane, epoch, sid), "rb") as f:
+            try:
+                f = open(self._stream_path(lane, epoch, sid), "rb")
+            except FileNotFoundError:
+                return None                                # retired by another worker between the index look-up and here: a miss, not an error
+            with f:
                 size = os.fstat(f.fileno()).st_size
                 m = mmap.mmap(f.fileno(), size, access=mmap.ACCESS_READ) if size else b""
             if len(self._maps) >= self.max_maps:
@@ -231,11 +312,21 @@ class FileSegmentStore:
             d = self._idx.get((lane, epoch), ({}, 0))[0]
             if any(fp not in d for fp in fps):
                 d = self._refresh(lane, epoch)
+            if d:
+                self._b.touched[(lane, epoch)] = time.monotonic()
             out = []
             for fp in fps:
                 h = d.get(fp)
-                out.append(None if h is None else (self._map(lane, epoch, h[0]), h[1], h[2]))
+                m = None if h is None else self._map(lane, epoch, h[0])
+                out.append(None if m is None else (m, h[1], h[2]))
             return out
+
+    def cleanup(self):
+        """The transfer is over (worker exit): the directory goes."""
+        with self._lock:
+            self._idx.clear()
+            self._maps.clear()
+        shutil.rmtree(self.dir, ignore_errors=True)
 
     def get(self, lane: int, epoch: int, fp: bytes) -> Optional[bytes]:
         (hit,) = self.get_many(lane, epoch, [fp])

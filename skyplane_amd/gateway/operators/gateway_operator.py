@@ -138,7 +138,7 @@ class GatewayHipCompress(GatewayOperator):
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
-                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: int = 3, fill_wait_s: float = 0.004,
+                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: float = 0.004,
                  prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
         # How a frame reaches the sender.  "arena": the device writes it by DMA into a slot of a shared, page-locked arena file in
@@ -166,7 +166,9 @@ class GatewayHipCompress(GatewayOperator):
         # whole-chunk MD5 is a serial chain of ~0.1 s per 8 MiB whatever the batch size: with one lane the worker would sit
         # in that call while the next batch waits; with several, lane B uploads and compresses while lane A's chain runs (the C ABI is
         # synchronous per context and ctypes releases the GIL, so lanes overlap on the device and in the kernel's file I/O).
-        self.pipeline_depth = max(1, int(pipeline_depth))
+        # Default 3; ONE lane when the source deduplicates on the wire: every lane owns a device context with its own fingerprint table (up to GiBs of
+        # HBM each) and duplicates that land on different lanes are never matched, so several lanes cost memory and hit rate.
+        self.pipeline_depth = max(1, int(pipeline_depth)) if pipeline_depth is not None else (1 if self.dedup_wire else 3)
         # a lane that finds fewer than max_batch requests waits this long once for more before it launches: trickling input otherwise
         # turns into many one-chunk calls that each pay the full chain latency
         self.fill_wait_s = float(fill_wait_s)
@@ -344,8 +346,31 @@ class GatewayHipCompress(GatewayOperator):
     def process(self, chunk_req: ChunkRequest, **args):
         return self.process_batch([chunk_req])[0]
 
+    def _parked(self) -> list:
+        """This lane's not-ready requests: [due time, attempts, request].  They wait HERE with an exponential back-off (10 ms ... 0.5 s) instead of
+        going straight back into the shared queue, where the next loop iteration would pick them up again at once."""
+        if not hasattr(self._tls, "parked"):
+            self._tls.parked = []
+        return self._tls.parked
+
+    def _park(self, cr: ChunkRequest):
+        parked = self._parked()
+        tries = getattr(self._tls, "tries", None)
+        if tries is None:
+            tries = self._tls.tries = {}
+        n = tries.get(cr.chunk.chunk_id, 0)
+        tries[cr.chunk.chunk_id] = n + 1
+        parked.append([time.monotonic() + min(0.5, 0.01 * (1 << min(n, 6))), n, cr])
+
     def _take_batch(self) -> List[ChunkRequest]:
         batch: List[ChunkRequest] = []
+        parked = self._parked()
+        if parked:
+            now = time.monotonic()
+            due = [e for e in parked if e[0] <= now]
+            for e in due[: self.max_batch]:
+                parked.remove(e)
+                batch.append(e[2])
         waited = False
         while len(batch) < self.max_batch:
             try:
@@ -400,15 +425,17 @@ class GatewayHipCompress(GatewayOperator):
                             self.output_queue.put(cr)
                     else:
                         retry.append(cr)
-                if retry:
-                    if len(retry) == len(batch):
-                        time.sleep(0.1)                # nothing could be done: wait like the reference does (:103-106)
-                    for cr in retry:
-                        self.input_queue.put(cr)
+                for cr in retry:
+                    self._park(cr)                     # comes back to this lane after its back-off (the reference sleeps 0.1 s and re-queues, :103-106)
+                if retry and len(retry) == len(batch):
+                    time.sleep(self.idle_sleep_s)      # nothing could be done this round
             except Exception:
                 self.error_queue.put(traceback.format_exc())
                 self.error_event.set()
                 self.exit_flags[worker_id].set()
+        for _due, _n, cr in self._parked():           # what still waits goes back to the queue: another worker (or a restart) may finish it
+            self.input_queue.put(cr)
+        self._parked().clear()
         self.worker_exit(worker_id)                    # this lane's context and arenas (thread-local)
 
     def worker_loop(self, worker_id: int, *args):
@@ -420,6 +447,10 @@ class GatewayHipCompress(GatewayOperator):
         self._lane_loop(worker_id)                     # the worker's own thread is lane 0
         for t in lanes:
             t.join()
+        self.process_exit(worker_id)
+
+    def process_exit(self, worker_id: int):
+        """Every lane of this worker process has left its loop."""
 
     def worker_exit(self, worker_id: int):
         w = getattr(self._tls, "writer", None)
@@ -465,6 +496,7 @@ class GatewayHipDecompress(GatewayHipCompress):
         self._store = None                     # created in the worker process, on the first recipe
         self._store_lock = threading.Lock()
         self._first_miss = {}
+        self._put_done = set()                 # chunk ids whose literal segments are in the store already (a retry must not store them again)
 
     def _segment_store(self) -> "dedup_wire.SegmentStore":
         with self._store_lock:
@@ -474,6 +506,11 @@ class GatewayHipDecompress(GatewayHipCompress):
                 else:
                     self._store = dedup_wire.SegmentStore()
             return self._store
+
+    def process_exit(self, worker_id: int):
+        if self._store is not None:            # the transfer is over for this process: what its segment store holds (RAM, or files in the chunk directory) goes
+            self._store.cleanup()
+            self._store = None
 
     @staticmethod
     def _expected_digest(chunk_req: ChunkRequest) -> Optional[bytes]:
@@ -500,14 +537,16 @@ class GatewayHipDecompress(GatewayHipCompress):
         lit = lit if isinstance(lit, np.ndarray) else np.frombuffer(lit, np.uint8)
         # this chunk's literals first: they may be what its own (or another waiting chunk's) references name
         li = np.nonzero(is_lit)[0]
-        if len(li):
+        if len(li) and cid not in self._put_done:      # once per chunk: a chunk that waits for a reference comes back here many times
             store.put_chunk(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in li], lit_start[li], lens[li], lit.tobytes())
+            self._put_done.add(cid)
         ri = np.nonzero(~is_lit)[0]
         hits = store.get_many(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in ri]) if len(ri) else []
         for k, h in zip(ri, hits):
             if h is None:
                 t0 = self._first_miss.setdefault(cid, time.monotonic())
                 if time.monotonic() - t0 > self.dedup_wait_s:
+                    self._put_done.discard(cid)
                     raise ValueError(f"[Gateway] chunk {cid}: segment {fpblob[16 * k:16 * k + 16].hex()} of lane {rec.lane:#x} epoch {rec.epoch} did not arrive "
                                      f"within {self.dedup_wait_s:.0f} s (is gpu_decompress running with more than one worker process?)")
                 return None
@@ -531,6 +570,7 @@ class GatewayHipDecompress(GatewayHipCompress):
                 j += 1
             out[out_start[k0]:out_start[k0] + (end - off)] = np.frombuffer(buf, np.uint8, end - off, off)
         self._first_miss.pop(cid, None)
+        self._put_done.discard(cid)
         return out
 
     def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
@@ -594,7 +634,10 @@ class GatewayHipDecompress(GatewayHipCompress):
                     raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: recipe for {rec.raw_len} bytes, expected {r}")
                 recipes[j] = rec
                 frames[j], raw_lens[j] = rec.lit_frame, rec.lit_raw_len
-        dec = [j for j in range(len(todo)) if recipes[j] is None or recipes[j].lit_raw_len]       # (a recipe of references only has nothing to decode)
+        # a recipe that was here before and had to wait left its decoded literal stream behind: no second decode for it
+        cache = self._tls.__dict__.setdefault("lit_cache", {})
+        cached = {j: cache[chunk_reqs[todo[j]].chunk.chunk_id] for j in range(len(todo)) if recipes[j] is not None and chunk_reqs[todo[j]].chunk.chunk_id in cache}
+        dec = [j for j in range(len(todo)) if (recipes[j] is None or recipes[j].lit_raw_len) and j not in cached]       # (a recipe of references only has nothing to decode)
         want = self.verify_md5 and any(self._expected_digest(chunk_reqs[i]) is not None for i in todo)
         want_dec = want and any(recipes[j] is None for j in dec)      # the digest of a literal stream is of no use (and costs a whole MD5 chain)
         kwargs = {"want_md5": True} if want_dec else {}
@@ -606,6 +649,8 @@ class GatewayHipDecompress(GatewayHipCompress):
             dd, gg = res if want_dec else (res, [None] * len(dec))
             for j, d, g in zip(dec, dd, gg):
                 datas[j], digests[j] = d, g
+        for j, lit in cached.items():
+            datas[j] = lit
         # recipes: rebuild; their digests are those of the rebuilt chunks (one more device call, MD5 only)
         ready = [True] * len(todo)
         rebuilt = []
@@ -614,10 +659,19 @@ class GatewayHipDecompress(GatewayHipCompress):
                 continue
             if len(datas[j]) != rec.lit_raw_len:
                 raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {len(datas[j])} bytes, the recipe says {rec.lit_raw_len}")
-            chunk = self._rebuild(chunk_reqs[todo[j]].chunk.chunk_id, rec, datas[j])
+            cid_j = chunk_reqs[todo[j]].chunk.chunk_id
+            try:
+                chunk = self._rebuild(cid_j, rec, datas[j])
+            except BaseException:
+                cache.pop(cid_j, None)
+                raise
             if chunk is None:
                 ready[j] = False
+                if cid_j not in cache and len(cache) < 4 * self.max_batch:
+                    d = datas[j]       # (bytes from a plain context, or a view of the staging arena that the next call reuses: keep a copy)
+                    cache[cid_j] = np.array(d, dtype=np.uint8, copy=True) if isinstance(d, np.ndarray) else np.frombuffer(bytes(d), np.uint8)
                 continue
+            cache.pop(cid_j, None)
             datas[j], digests[j] = chunk, None
             rebuilt.append(j)
         if want and rebuilt:

@@ -5,6 +5,7 @@ kernels' logic, LZ4 frames and MD5 too.  Covered: the recipe format and its reje
 source operator -> sidecar payloads -> destination operator byte for byte (and saving bytes), chunks arriving in the wrong order (a reference before
 its literal: "not ready", then resolved), epochs (table resets bound what the destination remembers), a reference that never resolves."""
 import hashlib
+import time
 import uuid
 from multiprocessing import Event, Queue
 
@@ -424,3 +425,89 @@ def test_dedup_wire_ragged_and_empty_chunks(tmp_path):
     assert all(dec.process_batch(reqs))
     for cr, c in zip(reqs, chunks):
         assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+
+
+# ---- round 3: the advisor's findings on the destination store ----
+def test_waiting_recipe_stores_its_literals_once_and_is_not_decoded_again(tmp_path):
+    """A chunk that waits for a reference comes back many times: its literal stream must be stored ONCE (dedup_store="files": one .lit file, not one
+    per retry) and decoded once (the decoded literals wait with it)."""
+    chunks = _dup_chunks()
+    src, dst, reqs = _stores(tmp_path, chunks)
+    ctx_dst = EmuDedupContext()
+    calls = {"n": 0}
+    real = ctx_dst.decompress_batch
+
+    def counting(frames, raw_lens, want_md5=False, into=None):
+        calls["n"] += len(frames)
+        return real(frames, raw_lens, want_md5=want_md5, into=into)
+
+    ctx_dst.decompress_batch = counting
+    ee, eq = Event(), Queue()
+    comp = GatewayHipCompress("gpu_compress_0", "local:t", GatewayQueue(), GatewayQueue(), ee, eq, src, n_processes=1, max_batch=8, max_chunk_bytes=4 << 20,
+                              device_ids=[0], context_factory=lambda d, mc, mb: EmuDedupContext(), dedup_wire=True)
+    dec = GatewayHipDecompress("gpu_decompress_0", "local:t", GatewayQueue(), GatewayQueue(), ee, eq, dst, n_processes=1, max_batch=8, max_chunk_bytes=4 << 20,
+                               device_ids=[0], context_factory=lambda d, mc, mb: ctx_dst, dedup_store="files")
+    assert comp.pipeline_depth == 1, "one lane (one fingerprint table) per deduplicating worker unless asked otherwise"
+    assert all(comp.process_batch(reqs))
+    _ship(src, dst, reqs)
+    late = [cr for cr in reqs[3:]]
+    oks = dec.process_batch(late)
+    waiting = [cr for cr, ok in zip(late, oks) if not ok]
+    assert waiting
+    seg_dir = dst.get_chunk_file_path("x").parent / "_segments"
+    n_lit, n_dec = len(list(seg_dir.glob("*.lit"))), calls["n"]
+    for _ in range(5):                                                     # the worker loop's retries
+        assert not any(dec.process_batch(waiting))
+    assert len(list(seg_dir.glob("*.lit"))) == n_lit and calls["n"] == n_dec
+    assert all(dec.process_batch(reqs[:3])) and all(dec.process_batch(waiting))
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+    dec.process_exit(0)
+    assert not seg_dir.exists(), "the segment store leaves with the worker"
+
+
+def test_segment_stores_are_bounded_and_distrust_epochs(tmp_path):
+    for store in (dedup_wire.SegmentStore(max_bytes=3000, idle_s=0), dedup_wire.FileSegmentStore(tmp_path / "seg", max_bytes=3000, idle_s=0)):
+        fp = lambda k: bytes([k]) * 16      # noqa: E731
+        for lane in (1, 2, 3, 4):           # 1000 bytes per lane: the fourth pushes the least recently used lane out
+            store.put_chunk(lane, 0, [fp(lane)], [0], [1000], bytes([lane]) * 1000)
+            if lane == 2:
+                assert store.get(1, 0, fp(1)) is not None       # touch lane 1: lane 2 is the oldest from now on
+        assert store.get(2, 0, fp(2)) is None and store.get(1, 0, fp(1)) == b"\x01" * 1000 and store.get(4, 0, fp(4)) is not None
+        # a known lane that claims an epoch far ahead is refused (it would retire everything the lane holds); a small step is normal
+        with pytest.raises(dedup_wire.RecipeError):
+            store.put_chunk(1, 0xFFFFFFFF, [fp(9)], [0], [10], b"x" * 10)
+        assert store.get(1, 0, fp(1)) is not None
+        store.put_chunk(1, 2, [fp(9)], [0], [10], b"y" * 10)
+        assert store.epochs_held(1) == [2] and store.get(1, 0, fp(1)) is None
+        store.cleanup()
+    # idle groups go when something else is written
+    s = dedup_wire.SegmentStore(idle_s=0.05)
+    s.put_chunk(7, 0, [b"a" * 16], [0], [4], b"abcd")
+    time.sleep(0.12)
+    s.put_chunk(8, 0, [b"b" * 16], [0], [4], b"efgh")
+    assert s.get(7, 0, b"a" * 16) is None and s.get(8, 0, b"b" * 16) == b"efgh"
+    # a literal stream retired by another worker between the index look-up and the open is a miss, not an exception
+    f = dedup_wire.FileSegmentStore(tmp_path / "seg2")
+    f.put_chunk(5, 0, [b"c" * 16], [0], [4], b"ijkl")
+    for p in (tmp_path / "seg2").glob("*.lit"):
+        p.unlink()
+    assert f.get_many(5, 0, [b"c" * 16]) == [None]
+
+
+def test_not_ready_chunks_wait_with_backoff_inside_the_lane(tmp_path):
+    src, dst, reqs = _stores(tmp_path, [b"x" * 2000, b"y" * 2000])
+    ee, eq = Event(), Queue()
+    dec = GatewayHipDecompress("gpu_decompress_0", "local:t", GatewayQueue(), GatewayQueue(), ee, eq, dst, n_processes=1, max_batch=8, max_chunk_bytes=4 << 20,
+                               device_ids=[0], context_factory=lambda d, mc, mb: EmuDedupContext())
+    dec.worker_id = 0
+    t0 = time.monotonic()
+    for _ in range(4):
+        dec._park(reqs[0])
+        (due, n, cr), = dec._parked()
+        dec._parked().clear()
+    assert n == 3 and 0.07 <= due - t0 <= 0.2                              # 10, 20, 40, 80 ms
+    dec._park(reqs[1])
+    assert dec._take_batch() == [] and len(dec._parked()) == 1             # not due yet: stays parked, the loop does not spin on it
+    time.sleep(0.02)
+    assert [c.chunk.chunk_id for c in dec._take_batch()] == [reqs[1].chunk.chunk_id] and not dec._parked()

@@ -87,7 +87,7 @@ def test_reference_daemons_plain_and_with_gpu_compress_operator():
     r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "512", "--connections", "2")
     assert r["verified"] and r["chunks"] == 6 and not r["gpu_op"]
     r = _run_daemon_harness("--chunks", "6", "--chunk-kib", "128", "--connections", "2", "--gpu-op")
-    assert r["verified"] and r["gpu_op"] and r["gpu_compress_chunks"] == 6
+    assert r["verified"] and r["gpu_op"] and 0 < r["gpu_compress_chunks_logged"] <= 6 and r["cpu_compress_calls_in_sender"] == 0
 
 
 def test_wire_header_differential_against_reference_chunk_py():
