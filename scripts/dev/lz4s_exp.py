@@ -9,7 +9,8 @@ n = int(os.environ.get("CHUNKS", "1024")); cb = synth.CHUNK_BYTES
 kind = os.environ.get("STREAM", "silesia")
 unit = synth.silesia_like(64 << 20, config_id=2) if kind == "silesia" else synth.mixed_chunks(8, cb, config_id=4).reshape(-1)
 d_unit = torch.from_numpy(unit).cuda()
-d_in = torch.empty(n * cb, dtype=torch.uint8, device="cuda")
+d_big = torch.zeros(n * cb + 8192, dtype=torch.uint8, device="cuda")      # slack on both sides: dev variants that read the block's neighbourhood from global memory
+d_in = d_big[4096:4096 + n * cb]
 for t in range(n * cb // unit.size):
     d_in[t * unit.size:(t + 1) * unit.size] = torch.roll(d_unit, -((t * 7919 * 4096 + t * 13) % unit.size) if kind == "silesia" else 0)
 stride = (hip_ops.frame_bound(cb) + 255) & ~255
