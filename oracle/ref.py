@@ -230,6 +230,52 @@ def lz4f_compress(data, store_size: bool = True, block_linked: bool = True, bloc
     return out[:n].tobytes()
 
 
+def lz4f_compress_stream(pieces, store_size: bool = True, block_linked: bool = True) -> bytes:
+    """A frame made the streaming way -- LZ4F_compressBegin, then LZ4F_compressUpdate + LZ4F_flush per piece, LZ4F_compressEnd -- as a producer
+    that flushes (python-lz4's LZ4FrameCompressor.flush()) makes it: every flush closes a block early, so the frame holds blocks SHORTER than the
+    block maximum in its middle.  A receiver must take such frames (lz4.frame.decompress does)."""
+    lib = liblz4()
+    lib.LZ4F_createCompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    lib.LZ4F_createCompressionContext.restype = C.c_size_t
+    lib.LZ4F_freeCompressionContext.argtypes = [C.c_void_p]
+    lib.LZ4F_compressBegin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_Prefs)]
+    lib.LZ4F_compressBegin.restype = C.c_size_t
+    lib.LZ4F_compressBound.argtypes = [C.c_size_t, C.POINTER(_Prefs)]
+    lib.LZ4F_compressBound.restype = C.c_size_t
+    lib.LZ4F_compressUpdate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.LZ4F_compressUpdate.restype = C.c_size_t
+    lib.LZ4F_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.LZ4F_flush.restype = C.c_size_t
+    lib.LZ4F_compressEnd.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.LZ4F_compressEnd.restype = C.c_size_t
+    pieces = [_buf(p) for p in pieces]
+    prefs = _Prefs()
+    prefs.frameInfo.contentSize = sum(p.size for p in pieces) if store_size else 0
+    prefs.frameInfo.blockMode = 0 if block_linked else 1
+    cctx = C.c_void_p()
+    r = lib.LZ4F_createCompressionContext(C.byref(cctx), 100)
+    if lib.LZ4F_isError(r):
+        raise OracleError(lib.LZ4F_getErrorName(r).decode())
+    try:
+        cap = 64 + sum(int(lib.LZ4F_compressBound(p.size, C.byref(prefs))) + 64 for p in pieces) + int(lib.LZ4F_compressBound(0, C.byref(prefs)))
+        out = np.empty(cap, np.uint8)
+        pos = 0
+
+        def chk(n):
+            if lib.LZ4F_isError(n):
+                raise OracleError(lib.LZ4F_getErrorName(n).decode())
+            return int(n)
+
+        pos += chk(lib.LZ4F_compressBegin(cctx, out.ctypes.data, cap, C.byref(prefs)))
+        for p in pieces:
+            pos += chk(lib.LZ4F_compressUpdate(cctx, out.ctypes.data + pos, cap - pos, p.ctypes.data if p.size else None, p.size, None))
+            pos += chk(lib.LZ4F_flush(cctx, out.ctypes.data + pos, cap - pos, None))
+        pos += chk(lib.LZ4F_compressEnd(cctx, out.ctypes.data + pos, cap - pos, None))
+        return out[:pos].tobytes()
+    finally:
+        lib.LZ4F_freeCompressionContext(cctx)
+
+
 def lz4f_compress_into(a: np.ndarray, out: np.ndarray) -> int:
     """Allocation-free variant for timing loops."""
     lib = liblz4()

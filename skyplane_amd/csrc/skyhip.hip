@@ -43,6 +43,15 @@ extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs 
 extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_lz4_decode(SkyLz4dRun r) { sky_lz4_decode_body(r); }
+extern "C" __global__ void __launch_bounds__(256) sky_lz4_parse(SkyLz4dLink r) { sky_lz4_parse_body(r); }
+extern "C" __global__ void __launch_bounds__(64) sky_lz4_link(SkyLz4dLink r) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4_link_body(r, smem);
+}
+extern "C" __global__ void __launch_bounds__(64) sky_lz4_decode_seq(SkyLz4dRun r) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4_decode_seq_body(r, smem);
+}
 #ifdef SKY_WITH_CDC
 extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) sky_gear_candidates(SkyGearArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -308,6 +317,7 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
             HIPCHK(c, c->d_blk_dst[k].ensure(nb));
         }
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_link, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4D_LINK_LDS));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
         HIPCHK(c, c->d_queue.ensure(16));

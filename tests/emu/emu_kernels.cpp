@@ -76,6 +76,9 @@ uint32_t emu_slot_bytes(void) { return SKY_LZ4_SLOT; }
 
 static void k_dscan(void* a, uint8_t*) { sky_lz4f_scan_body(*(SkyLz4dArgs*)a); }
 static void k_ddec(void* a, uint8_t*) { sky_lz4_decode_body(*(SkyLz4dRun*)a); }
+static void k_dseq(void* a, uint8_t* smem) { sky_lz4_decode_seq_body(*(SkyLz4dRun*)a, smem); }
+static void k_dparse(void* a, uint8_t*) { sky_lz4_parse_body(*(SkyLz4dLink*)a); }
+static void k_dlink(void* a, uint8_t* smem) { sky_lz4_link_body(*(SkyLz4dLink*)a, smem); }
 
 // mirrors sky_lz4d_run: scan, build work items, decode.  status[i] = decoder code, out_len[i] = decoded bytes.
 int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, int n, uint8_t* out, const uint64_t* out_off,
@@ -83,22 +86,51 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
     std::vector<sky_u64> ioff(in_off, in_off + n), ilen(in_len, in_len + n), ooff(out_off, out_off + n), ocap(out_cap, out_cap + n), content(n);
     std::vector<uint32_t> prefix(n + 1), nblk(n), flags(n), bmax(n), err(n);
     uint32_t slots = 0;
-    for (int i = 0; i < n; i++) { prefix[i] = slots; slots += (uint32_t)(ocap[i] / SKY_LZ4_BLOCK) + 2; }
+    for (int i = 0; i < n; i++) { prefix[i] = slots; slots += 2 * (uint32_t)(ocap[i] / SKY_LZ4_BLOCK) + 16; }
     prefix[n] = slots;
     std::vector<sky_u64> bsrc(slots); std::vector<uint32_t> bword(slots), bframe(slots);
     SkyLz4dArgs a; a.in = in; a.in_off = ioff.data(); a.in_len = ilen.data(); a.out = out; a.out_off = ooff.data(); a.out_cap = ocap.data();
     a.blk_prefix = prefix.data(); a.n = (uint32_t)n; a.f_nblk = nblk.data(); a.f_flags = flags.data(); a.f_bmax = bmax.data(); a.f_content = content.data();
     a.f_err = err.data(); a.b_src = bsrc.data(); a.b_word = bword.data(); a.b_frame = bframe.data(); a.n_slots = slots;
     emu_launch((n + 63) / 64, 64, 0, k_dscan, &a);
-    std::vector<uint32_t> items;
+    std::vector<uint32_t> items, seq, lframes, lfirst, litems;
+    auto kind = [&](int i) -> int {        // see sky_lz4d_run
+        if (!nblk[i]) return 0;
+        const bool b64 = bmax[i] == SKY_LZ4_BLOCK;
+        if ((flags[i] & 4u) && b64) return 'C';
+        if (!(flags[i] & 1u) && !(flags[i] & 4u) && b64) return 'B';
+        if ((flags[i] & 1u) && !(flags[i] & 4u)) return 'A';
+        return 'D';
+    };
     for (int i = 0; i < n; i++) {
-        if (!nblk[i]) continue;
-        if (flags[i] & 1u) for (uint32_t b = 0; b < nblk[i]; b++) items.push_back(prefix[i] + b);
-        else items.push_back((uint32_t)i | 0x80000000u);
+        const int k = kind(i);
+        if (k == 'C') seq.push_back((uint32_t)i);
+        else if (k == 'A') for (uint32_t b = 0; b < nblk[i]; b++) items.push_back(prefix[i] + b);
+        else if (k == 'D') items.push_back((uint32_t)i | 0x80000000u);
+        else if (k == 'B') { lframes.push_back((uint32_t)i); lfirst.push_back((uint32_t)litems.size()); for (uint32_t b = 0; b < nblk[i]; b++) litems.push_back(prefix[i] + b); }
+    }
+    if (!lframes.empty()) {
+        std::vector<sky_u64> desc((size_t)litems.size() * SKY_D_DESC_CAP);
+        std::vector<uint32_t> ndesc(litems.size());
+        SkyLz4dLink r; r.a = a; r.item_slot = litems.data(); r.n_items = (uint32_t)litems.size(); r.desc = desc.data(); r.ndesc = ndesc.data();
+        r.frames = lframes.data(); r.first_item = lfirst.data(); r.n_frames = (uint32_t)lframes.size();
+        emu_launch(((int)litems.size() + 3) / 4, 256, 0, k_dparse, &r);
+        emu_launch((int)lframes.size(), 64, SKY_LZ4D_LINK_LDS, k_dlink, &r);
     }
     if (!items.empty()) {
         SkyLz4dRun r; r.a = a; r.item_slot = items.data(); r.n_items = (uint32_t)items.size();
         emu_launch(((int)items.size() + 3) / 4, 256, 0, k_ddec, &r);
+    }
+    if (!seq.empty()) {
+        SkyLz4dRun r; r.a = a; r.item_slot = seq.data(); r.n_items = (uint32_t)seq.size();
+        emu_launch((int)seq.size(), 64, SKY_LZ4D_SEQ_LDS, k_dseq, &r);
+    }
+    seq.clear();       // frames without a content size that turned out to hold short blocks: second, sequential decode (see sky_lz4d_run)
+    for (int i = 0; i < n; i++)
+        if (err[i] != 0u && (kind(i) == 'A' || kind(i) == 'B') && (flags[i] & 2u) && nblk[i] > 1u && bmax[i] == SKY_LZ4_BLOCK) { seq.push_back((uint32_t)i); err[i] = 0; }
+    if (!seq.empty()) {
+        SkyLz4dRun r; r.a = a; r.item_slot = seq.data(); r.n_items = (uint32_t)seq.size();
+        emu_launch((int)seq.size(), 64, SKY_LZ4D_SEQ_LDS, k_dseq, &r);
     }
     int rc = 0;
     for (int i = 0; i < n; i++) { status[i] = (int32_t)err[i]; out_len[i] = err[i] ? 0 : content[i]; if (err[i]) rc = -8; }

@@ -108,3 +108,25 @@ def test_emu_decode_large_block_sizes(bsid, bmax):
               ref.lz4f_compress(d, store_size=False, block_size_id=bsid)]
     rc, outs, status = emulib.decompress(frames, [len(d)] * 3)
     assert rc == 0 and status == [0, 0, 0] and outs == [d, d, d]
+
+
+def test_frames_with_short_blocks_in_the_middle():
+    """A producer that flushes (LZ4F_flush; python-lz4's LZ4FrameCompressor.flush) closes blocks early: the frame holds blocks shorter than the
+    block maximum in its middle.  lz4.frame.decompress (gateway_receiver.py:195-201) takes them; round 2's decoder did not.
+    Linked and independent, with and without a content size -- the last one is only found out while decoding (second, sequential pass)."""
+    d = synth.gen_class("text", 300_000, synth.rng_for(5)).tobytes() + bytes(70_000) + synth.gen_class("records", 100_000, synth.rng_for(6)).tobytes()
+    cuts = [0, 70_000, 70_001, 200_000, 200_013, 330_000, len(d)]
+    pieces = [d[a:b] for a, b in zip(cuts, cuts[1:])]
+    frames, want = [], []
+    for linked in (True, False):
+        for sized in (True, False):
+            f = ref.lz4f_compress_stream(pieces, store_size=sized, block_linked=linked)
+            assert ref.lz4f_decompress(f, len(d)) == d
+            frames.append(f); want.append(d)
+    frames.append(ref.lz4f_compress(d)); want.append(d)                       # a regular frame in the same batch
+    rc, outs, status = emulib.decompress(frames, [len(w) for w in want])
+    assert rc == 0 and status == [0] * len(frames) and outs == want
+    # truncated / corrupted irregular frames are still rejected, and nothing is written past the capacity
+    bad = frames[3][:-5]
+    rc, outs, status = emulib.decompress([bad, frames[0]], [len(d), len(d) - 1])
+    assert rc != 0 and status[0] != 0 and status[1] != 0
