@@ -445,9 +445,10 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         ma.in = (const uint8_t*)d_in; ma.off = c->d_in_off.p; ma.len = c->d_in_len.p; ma.n = (uint32_t)N; ma.digest = c->d_md5.p;
         EvPair ep;
         if ((rc = ev_begin(c, c->s_md5, K_MD5, &ep))) return rc;
-        // one wave per CU is the fastest placement (82 ms per 8 MiB); two per CU cost 13 % of chain speed but leave twice as many CUs to the compressor,
-        // whose workgroups need a CU's whole register file: worth it once the digests alone would take more than a quarter of the chip
-        const int wg = (c->md5_wg_env || N <= (size_t)16 * c->lz4s_grid) ? c->md5_wg : 128;
+        // one wave per workgroup: a CU's memory path serves ONE such wave at full chain speed (82 ms per 8 MiB; 94 ms with two, profiles/r2_md5_workgroup.txt).
+        // Round 2 switched to two waves per workgroup above 4096 chunks to leave more CUs free of MD5; measured again in round 3 (GPU call r3n) the step
+        // is 1.9 % shorter with one (177.95 against 181.3 ms for 8192 chunks) and equal for 16384: the chain, not the co-residency, is what to protect.
+        const int wg = c->md5_wg;
         hipLaunchKernelGGL(sky_md5_chunks, dim3((unsigned)((N + (size_t)wg - 1) / (size_t)wg)), dim3((unsigned)wg), 0, c->s_md5, ma);
         HIPCHK(c, hipGetLastError());
         if ((rc = ev_end(c, c->s_md5, ep))) return rc;
