@@ -137,6 +137,8 @@ def main():
                                                                                    "shared page-locked arena (gateway/shm_arena.py) or one tmpfs file per chunk")
     ap.add_argument("--dedup-wire", action="store_true", help="dedup on the wire (gateway/dedup_wire.py): a 50 %%-duplicate stream, recipes instead of frames, "
                                                             "one destination worker process (its lanes share the segment store)")
+    ap.add_argument("--dedup-store", choices=["memory", "files"], default="memory", help="--dedup-wire: where the destination keeps literal segments -- in the "
+                    "one worker process (memory) or in files of the chunk directory shared by --workers processes")
     a = ap.parse_args()
     if a.dedup_wire:
         os.environ["E2E_DEDUP_WIRE"] = "1"
@@ -176,8 +178,8 @@ def main():
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
                                 max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, **kw)
-        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if a.dedup_wire else a.workers,
-                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], **kw)
+        dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
+                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
         go = threading.Event()
@@ -275,7 +277,7 @@ def main():
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null"}))
 

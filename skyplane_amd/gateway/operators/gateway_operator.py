@@ -318,6 +318,9 @@ class GatewayHipCompress(GatewayOperator):
         in_len = np.array([len(d) for d in datas], np.uint64)
         prefix, cuts, fps, first, base = ctx.cdc_results(len(datas), in_len)
         plans, lit_bufs, lit_owner = [], [], []
+        # the literal streams of chunks with duplicates are gathered straight into pinned staging (the second device call then uploads asynchronously)
+        lit_arena = self._arena(ctx, "lit", sum((len(d) + 255) & ~255 for d in datas)) if hasattr(ctx, "pinned_buffer") else None
+        lit_pos = 0
         for i, (data, res) in enumerate(zip(datas, results)):
             lens, kinds, sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
             if not kinds.any():                        # nothing to leave out: the frame the compressor made IS the literal stream
@@ -326,7 +329,13 @@ class GatewayHipCompress(GatewayOperator):
             arr = data if isinstance(data, np.ndarray) else np.frombuffer(data, np.uint8)
             ends = np.cumsum(lens.astype(np.int64))
             parts = [arr[e - l:e] for e, l, kd in zip(ends, lens, kinds) if kd == dedup_wire.KIND_LITERAL]
-            lit = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+            if parts and lit_arena is not None:
+                nlit = int(sum(p.size for p in parts))
+                lit = lit_arena[lit_pos:lit_pos + nlit]
+                np.concatenate(parts, out=lit)
+                lit_pos += (nlit + 255) & ~255
+            else:
+                lit = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
             plans.append([lens, kinds, fps[sl], b"", int(lit.size)])
             if lit.size:
                 lit_bufs.append(lit)
@@ -521,7 +530,7 @@ class GatewayHipDecompress(GatewayHipCompress):
             return bytes.fromhex(h)
         return bytes(h)
 
-    def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit) -> Optional[np.ndarray]:
+    def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream.  Runs of literal
         segments and runs of references into one earlier literal stream are each one copy; the only per-segment work is a dictionary look-up."""
         store = self._segment_store()
@@ -552,7 +561,7 @@ class GatewayHipDecompress(GatewayHipCompress):
                 return None
             if h[2] != lens[k]:
                 raise ValueError(f"[Gateway] chunk {cid}: referenced segment {fpblob[16 * k:16 * k + 16].hex()} has {h[2]} bytes, the recipe says {int(lens[k])}")
-        out = np.empty(rec.raw_len, np.uint8)
+        out = np.empty(rec.raw_len, np.uint8) if out is None else out[:rec.raw_len]      # (a view of pinned staging when the caller has one: the digest call uploads from it)
         # literal runs: segments k..m literal <=> one contiguous piece of the literal stream
         if len(li):
             brk = np.nonzero(np.diff(li) != 1)[0]
@@ -654,6 +663,9 @@ class GatewayHipDecompress(GatewayHipCompress):
         # recipes: rebuild; their digests are those of the rebuilt chunks (one more device call, MD5 only)
         ready = [True] * len(todo)
         rebuilt = []
+        n_rec_bytes = sum((recipes[j].raw_len + 255) & ~255 for j in range(len(todo)) if recipes[j] is not None)
+        reb_arena = self._arena(ctx, "rebuilt", n_rec_bytes) if (pinned and n_rec_bytes) else None
+        reb_pos = 0
         for j, rec in enumerate(recipes):
             if rec is None:
                 continue
@@ -661,7 +673,11 @@ class GatewayHipDecompress(GatewayHipCompress):
                 raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {len(datas[j])} bytes, the recipe says {rec.lit_raw_len}")
             cid_j = chunk_reqs[todo[j]].chunk.chunk_id
             try:
-                chunk = self._rebuild(cid_j, rec, datas[j])
+                slot = None
+                if reb_arena is not None:
+                    slot = reb_arena[reb_pos:reb_pos + rec.raw_len]
+                    reb_pos += (rec.raw_len + 255) & ~255
+                chunk = self._rebuild(cid_j, rec, datas[j], out=slot)
             except BaseException:
                 cache.pop(cid_j, None)
                 raise
