@@ -21,10 +21,9 @@
 #define LZ4S_LOGB 12           // log2 buckets; table = buckets x Q entries of 4 bytes = 64 KiB
 #endif
 #ifndef LZ4S_EXT
-#define LZ4S_EXT 128u          // a match may run this far past the end of its slice (overlaps are trimmed afterwards; a match that goes on is continued by the
-                               // next slices' own matches and merged back into one sequence by the stitch).  256 until round 3: 128 costs 0.03 % of ratio on the
-                               // Silesia-like stream and takes 1.0 % off the kernel (fewer 16-byte extension steps); 64 would take 1.8 % but makes the sparse
-                               // class 14 % larger than liblz4's frames (tests/test_emu_kernels.py holds every class within 10 %): profiles/r3_lz4s_variants.txt
+#define LZ4S_EXT 256u          // a match may run this far past the end of its slice (overlaps are trimmed afterwards).  Measured again in round 3: 128 takes 1.0 % and 64
+                               // takes 1.8 % off the kernel for 0.03 % / 0.09 % of ratio on the Silesia-like stream, but sparse data (long runs) then exceeds the reference's
+                               // frames by 10.1 % / 14.6 % against 8.4 % -- over the 10 % every class is held to (tests/test_gpu_parity.py): stays at 256
 #endif
 #ifndef LZ4S_BACK
 #define LZ4S_BACK 8u           // a match start may move back over at most this many pending literals
