@@ -44,7 +44,7 @@ extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs 
 extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_lz4_decode(SkyLz4dRun r) { sky_lz4_decode_body(r); }
 extern "C" __global__ void __launch_bounds__(256) sky_lz4_parse(SkyLz4dLink r) { sky_lz4_parse_body(r); }
-extern "C" __global__ void __launch_bounds__(64) sky_lz4_link(SkyLz4dLink r) {
+extern "C" __global__ void __launch_bounds__(SKY_LZ4D_LINK_LANES) sky_lz4_link(SkyLz4dLink r) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_link_body(r, smem);
 }

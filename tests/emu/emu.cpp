@@ -103,6 +103,7 @@ void emu_launch(int grid, int block, size_t lds_bytes, EmuKernelBody body, void*
                     }
                     if (!live) { finished[w] = 1; break; }
                     if (op == EMU_BARRIER) { at_barrier[w] = 1; break; }
+                    if (op == EMU_YIELD) break;      // resumed on the scheduler's next pass over the wavefronts
                     switch (op) {
                     case EMU_BALLOT: {
                         sky_u64 m = 0;

@@ -115,7 +115,7 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
         SkyLz4dLink r; r.a = a; r.item_slot = litems.data(); r.n_items = (uint32_t)litems.size(); r.desc = desc.data(); r.ndesc = ndesc.data();
         r.frames = lframes.data(); r.first_item = lfirst.data(); r.n_frames = (uint32_t)lframes.size();
         emu_launch(((int)litems.size() + 3) / 4, 256, 0, k_dparse, &r);
-        emu_launch((int)lframes.size(), 64, SKY_LZ4D_LINK_LDS, k_dlink, &r);
+        emu_launch((int)lframes.size(), (int)SKY_LZ4D_LINK_LANES, SKY_LZ4D_LINK_LDS, k_dlink, &r);
     }
     if (!items.empty()) {
         SkyLz4dRun r; r.a = a; r.item_slot = items.data(); r.n_items = (uint32_t)items.size();

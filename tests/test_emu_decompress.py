@@ -130,3 +130,27 @@ def test_frames_with_short_blocks_in_the_middle():
     bad = frames[3][:-5]
     rc, outs, status = emulib.decompress([bad, frames[0]], [len(d), len(d) - 1])
     assert rc != 0 and status[0] != 0 and status[1] != 0
+
+
+def link_stress_cases():
+    """Blocks built to stress the link pass (sky_lz4_link): more matches than one super-batch holds (> 7168 per 64 KiB block), chains of matches that each
+    copy the output of the one before, matches that reach across the block boundary, long runs next to very short matches."""
+    rng = np.random.default_rng(77)
+    words = [rng.integers(0, 256, 5, dtype=np.uint8).tobytes() for _ in range(200)]
+    many = b"".join(words[int(k)] + bytes([int(b)]) for k, b in zip(rng.integers(0, 200, 40_000), rng.integers(0, 256, 40_000)))     # a match every 6 bytes
+    chain = bytearray(rng.integers(0, 256, 37, dtype=np.uint8).tobytes())
+    while len(chain) < 200_000:                                        # every piece copies a recent piece and changes one byte: long dependency chains
+        back = int(rng.integers(20, 37)); n = int(rng.integers(8, 30))
+        chain += bytes(chain[-back:][:n]) + bytes([int(rng.integers(0, 256))])
+    chain = bytes(chain)
+    straddle = (rng.integers(0, 256, 65_500, dtype=np.uint8).tobytes() + b"Q" * 300) * 3 + bytes(70_000) + many[:50_000]
+    return [many, chain, straddle, many[:70_000] + bytes(100_000) + chain[:70_000]]
+
+
+def test_emu_linked_frames_with_many_and_chained_matches():
+    """The link pass -- 16 wavefronts per frame, a match copied as soon as the matches it reads from are done -- against liblz4's linked frames."""
+    cases = link_stress_cases()
+    frames = [ref.lz4f_compress(c) for c in cases]                     # python-lz4's defaults: linked blocks
+    rc, outs, status = emulib.decompress(frames, [len(c) for c in cases])
+    assert rc == 0 and status == [0] * len(cases)
+    assert outs == cases

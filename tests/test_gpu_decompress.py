@@ -148,3 +148,15 @@ def test_decode_frames_with_short_blocks_in_the_middle(ctx):
     assert outs == [d] * len(frames) and digs == [hashlib.md5(d).digest()] * len(frames)
     with pytest.raises(hip_ops.SkyHipError):
         ctx.decompress_batch([frames[3][:-5]], [len(d)])
+
+
+def test_decode_linked_frames_with_many_and_chained_matches(ctx):
+    """sky_lz4_link's dependency tracking on the hardware (the emulator runs the same cases: tests/test_emu_decompress.py), several frames per launch and
+    twice in a row (the flags live in LDS, nothing may survive a launch)."""
+    from tests.test_emu_decompress import link_stress_cases
+
+    cases = link_stress_cases() * 3
+    frames = [ref.lz4f_compress(c) for c in cases]
+    for _ in range(2):
+        outs = ctx.decompress_batch(frames, [len(c) for c in cases])
+        assert outs == cases
