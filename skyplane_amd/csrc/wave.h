@@ -106,24 +106,13 @@ SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(
 // LDS atomics (workgroup scope): ds_min_u32 without return, ds_add_rtn_u32
 SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// flags in LDS that one wavefront of a workgroup sets and the others poll (sky_lz4_link): a ds_or after the writer's earlier LDS stores have completed
-// (sky_wg_release: s_waitcnt), a real ds_read per poll, and the reader's later loads stay behind it (sky_wg_acquire); sky_wave_yield gives the SIMD to the
+// flags in LDS that one wavefront of a workgroup stores and the others poll (sky_lz4_link): a real ds_read per poll; sky_wave_yield gives the SIMD to the
 // wavefronts that are being waited for
-SKY_DEV void sky_lds_or_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV uint32_t sky_lds_poll_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-SKY_DEV void sky_wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-SKY_DEV void sky_wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-#ifndef SKY_YIELD_SLEEP
-#define SKY_YIELD_SLEEP 1
-#endif
-SKY_DEV void sky_wave_yield() { __builtin_amdgcn_s_sleep(SKY_YIELD_SLEEP); }
+SKY_DEV void sky_wave_yield() { __builtin_amdgcn_s_sleep(1); }
 // compiler-only ordering of this wavefront's LDS accesses: the DS queue of a wavefront is served in order, so a load issued after a store sees it and a
 // flag stored after data is seen after it -- nothing to wait for (sky_wave_fence costs an s_waitcnt lgkmcnt(0))
-#ifdef SKY_LINK_WAITFENCE      // (scripts/dev comparison build)
-SKY_DEV void sky_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-#else
 SKY_DEV void sky_lds_order() { asm volatile("" ::: "memory"); }
-#endif
 SKY_DEV sky_u64 sky_atomic_min_u64(sky_u64* p, sky_u64 v) { return atomicMin(p, v); }
 SKY_DEV sky_u64 sky_atomic_cas_u64(sky_u64* p, sky_u64 expect, sky_u64 desired) { return atomicCAS(p, expect, desired); }
 SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
