@@ -271,13 +271,21 @@ def main():
             got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
             assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
         raw = a.chunks * size
+        # the rate between the first and the last quarter of the chunks leaving the destination operator: what a transfer of minutes sees, without this
+        # run's pipeline fill (the first device call of each side: ~0.1 s each, one MD5 chain) and drain
+        dts = sorted(t - t0 for t in trace["decoded"] if t >= t0)
+        steady = None
+        if len(dts) >= 64:
+            q1, q3 = dts[len(dts) // 4], dts[(3 * len(dts)) // 4]
+            if q3 > q1:
+                steady = round(((3 * len(dts)) // 4 - len(dts) // 4) * size * 8 / (q3 - q1) / 1e9, 3)
         if os.environ.get("E2E_TRACE"):
             for name, ts in trace.items():
                 ts = sorted(t - t0 for t in ts if t >= t0)
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null"}))
 

@@ -22,6 +22,7 @@ from __future__ import annotations
 import os
 import queue
 import random
+import sys
 import threading
 import time
 import traceback
@@ -35,6 +36,9 @@ from skyplane_amd.chunk import ChunkRequest, ChunkState
 from skyplane_amd.gateway import dedup_wire, shm_arena, sidecar
 from skyplane_amd.gateway.chunk_store import ChunkStore
 from skyplane_amd.gateway.gateway_queue import GatewayQueue
+
+
+_OP_TRACE = bool(os.environ.get("SKY_OP_TRACE"))
 
 
 class GatewayOperator(ABC):
@@ -138,7 +142,7 @@ class GatewayHipCompress(GatewayOperator):
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
-                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: float = 0.004,
+                 idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: Optional[float] = None,
                  prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
         # How a frame reaches the sender.  "arena": the device writes it by DMA into a slot of a shared, page-locked arena file in
@@ -169,9 +173,10 @@ class GatewayHipCompress(GatewayOperator):
         # Default 3; ONE lane when the source deduplicates on the wire: every lane owns a device context with its own fingerprint table (up to GiBs of
         # HBM each) and duplicates that land on different lanes are never matched, so several lanes cost memory and hit rate.
         self.pipeline_depth = max(1, int(pipeline_depth)) if pipeline_depth is not None else (1 if self.dedup_wire else 3)
-        # a lane that finds fewer than max_batch requests waits this long once for more before it launches: trickling input otherwise
-        # turns into many one-chunk calls that each pay the full chain latency
-        self.fill_wait_s = float(fill_wait_s)
+        # a lane that finds fewer than max_batch requests keeps collecting for up to this long before it launches: trickling input otherwise turns into
+        # many small calls that each pay the full chain latency (~80 ms).  30 ms with three lanes per worker (another lane is on the device meanwhile);
+        # 4 ms for the single lane of the dedup path, where a waiting lane is an idle device (profiles/r3_e2e_fill_wait.txt)
+        self.fill_wait_s = float(fill_wait_s) if fill_wait_s is not None else (0.004 if self.dedup_wire else 0.03)
         # size every lane's pinned arenas for max_batch chunks of max_chunk_bytes when the lane starts, instead of growing them under the first full
         # batches: pinning fresh host memory runs at a few GB/s, which a transfer of seconds would otherwise pay inside its first batches
         self.prealloc = bool(prealloc)
@@ -380,16 +385,21 @@ class GatewayHipCompress(GatewayOperator):
             for e in due[: self.max_batch]:
                 parked.remove(e)
                 batch.append(e[2])
-        waited = False
+        # A device call costs ~80 ms whatever it holds (the MD5 of an 8 MiB chunk is one serial chain), so a call per straggler is the expensive way to be
+        # prompt: once there is something to do, keep collecting for up to fill_wait_s (profiles/r3_e2e_fill_wait.txt), less when the batch fills up
+        deadline = None
         while len(batch) < self.max_batch:
             try:
                 batch.append(self.input_queue.get_nowait(self.handle))
             except queue.Empty:
-                if batch and not waited and self.fill_wait_s > 0:
-                    waited = True
-                    time.sleep(self.fill_wait_s)       # one short wait for stragglers, then go with what is there
-                    continue
-                break
+                if not batch or self.fill_wait_s <= 0:
+                    break
+                now = time.monotonic()
+                if deadline is None:
+                    deadline = now + self.fill_wait_s
+                if now >= deadline:
+                    break
+                time.sleep(min(0.002, deadline - now))
         return batch
 
     def _prealloc(self):
@@ -586,6 +596,7 @@ class GatewayHipDecompress(GatewayHipCompress):
         ctx = self._context()
         oks = [False] * len(chunk_reqs)
         self._last_metadata = [{} for _ in chunk_reqs]
+        trace = [time.perf_counter()] if _OP_TRACE else None      # SKY_OP_TRACE=1: where a batch's time goes, one line per batch on stderr
         todo = []                                      # indices whose payload is there
         for i, cr in enumerate(chunk_reqs):
             cid = cr.chunk.chunk_id
@@ -653,6 +664,8 @@ class GatewayHipDecompress(GatewayHipCompress):
         if into is not None:
             kwargs["into"] = [into[j] for j in dec]
         datas, digests = [np.zeros(0, np.uint8)] * len(todo), [None] * len(todo)
+        if trace:
+            trace.append(time.perf_counter())
         if dec:
             res = ctx.decompress_batch([frames[j] for j in dec], [raw_lens[j] for j in dec], **kwargs)
             dd, gg = res if want_dec else (res, [None] * len(dec))
@@ -660,6 +673,8 @@ class GatewayHipDecompress(GatewayHipCompress):
                 datas[j], digests[j] = d, g
         for j, lit in cached.items():
             datas[j] = lit
+        if trace:
+            trace.append(time.perf_counter())
         # recipes: rebuild; their digests are those of the rebuilt chunks (one more device call, MD5 only)
         ready = [True] * len(todo)
         rebuilt = []
@@ -693,6 +708,8 @@ class GatewayHipDecompress(GatewayHipCompress):
         if want and rebuilt:
             for j, r in zip(rebuilt, ctx.process_batch([datas[j] for j in rebuilt], flags=2)):
                 digests[j] = r.md5
+        if trace:
+            trace.append(time.perf_counter())
         for j, (i, p, data, dig, size) in enumerate(zip(todo, paths, datas, digests, sizes)):
             if not ready[j]:
                 continue                               # re-queued by the worker loop; its literals are already in the store
@@ -716,4 +733,8 @@ class GatewayHipDecompress(GatewayHipCompress):
                 meta["dedup_reference_bytes"] = int(recipes[j].raw_len - recipes[j].lit_raw_len)
             self._last_metadata[i] = meta
             oks[i] = True
+        if trace:
+            t = trace + [time.perf_counter()]
+            print(f"[op-trace] {self.handle} pid {os.getpid()} {threading.current_thread().name}: {len(todo)} chunks at {t[0]:.3f}: open+stage {1e3 * (t[1] - t[0]):.1f} ms, "
+                  f"device {1e3 * (t[2] - t[1]):.1f}, rebuild+digest {1e3 * (t[3] - t[2]):.1f}, write {1e3 * (t[4] - t[3]):.1f}", file=sys.stderr, flush=True)
         return oks
