@@ -139,6 +139,8 @@ def main():
                                                             "one destination worker process (its lanes share the segment store)")
     ap.add_argument("--dedup-store", choices=["memory", "files"], default="memory", help="--dedup-wire: where the destination keeps literal segments -- in the "
                     "one worker process (memory) or in files of the chunk directory shared by --workers processes")
+    ap.add_argument("--dst-depth", type=int, default=0, help="pipeline lanes per destination worker (0 = the operator's default)")
+    ap.add_argument("--src-depth", type=int, default=0, help="pipeline lanes per source worker (0 = the operator's default)")
     a = ap.parse_args()
     if a.dedup_wire:
         os.environ["E2E_DEDUP_WIRE"] = "1"
@@ -170,16 +172,16 @@ def main():
         main_reqs = [make(K + i) for i in range(a.chunks)]
         shares = [[warm[k]] + main_reqs[k::K] for k in range(K)]
         port_q, done_q = Queue(), Queue()
-        rx = Process(target=receiver_main, args=(dst, port_q, done_q, K, (2 * a.max_batch * max(a.workers, 1) + K) if a.handoff == "arena" else 0, size))
+        rx = Process(target=receiver_main, args=(dst, port_q, done_q, K, (max(2, a.dst_depth or 3) * a.max_batch * max(a.workers, 1) + K) if a.handoff == "arena" else 0, size))
         rx.start()
         port = port_q.get(timeout=120)
         err_ev, err_q = Event(), Queue()
         kw = {"context_factory": factory} if factory else {}
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
-                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, **kw)
+                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, pipeline_depth=a.src_depth or None, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
-                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, **kw)
+                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
         go = threading.Event()
@@ -285,7 +287,7 @@ def main():
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "src_depth": a.src_depth or None, "dst_depth": a.dst_depth or None, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null"}))
 
