@@ -503,3 +503,26 @@ def test_steady_state_e2e_script_with_emulated_device():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["verified"] and r["chunks"] == 10 and r["workers"] == 2
+
+
+def test_lanes_collect_before_a_call(tmp_path):
+    """_take_batch: a trickle of requests is collected for up to fill_wait_s instead of becoming one device call per request (a call costs ~80 ms
+    whatever it holds: the MD5 of an 8 MiB chunk is one serial chain; profiles/r3_e2e_fill_wait.txt), and a full batch does not wait at all."""
+    import threading
+    import time
+
+    store, q_in, q_out, reqs = _make_store(tmp_path, 48)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "r", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=32, device_ids=[0], context_factory=_factory, fill_wait_s=0.3)
+    feeder = threading.Thread(target=lambda: [(time.sleep(0.02), store.add_chunk_request(cr)) for cr, _ in reqs[:6]])
+    feeder.start()
+    got = []
+    while not got:
+        got = op._take_batch()
+    feeder.join()
+    assert len(got) >= 5                                            # ONE batch for the trickle (the sixth request may still be in the queue's pipe)
+    for cr, _ in reqs[6:48]:
+        store.add_chunk_request(cr)
+    time.sleep(0.2)                                                 # (multiprocessing.Queue.put hands over to a feeder thread)
+    t = time.monotonic()
+    assert len(op._take_batch()) == 32 and time.monotonic() - t < 0.1
