@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""Analysis (not a test, CPU only): how deep are the chains of copies-of-copies in liblz4's block-linked frames, and what does pointer jumping buy?
+
+For the first blocks of an 8 MiB Silesia-like chunk compressed the way a stock reference sender does (lz4.frame.compress defaults, oracle/ref.py), every match
+becomes a descriptor (destination, offset, length); depth[d] = 1 + the maximum depth of the matches whose destinations d's source touches.  That depth -- not
+the number of matches -- bounds sky_lz4_link (csrc/lz4d_kernel.inc): a level costs a wavefront ~800 cycles whatever the lane count.  Then the shortening the
+kernel applies is simulated: a short plain copy whose source lies inside the destination of ONE earlier plain copy reads that copy's source instead and
+inherits its range.  Printed per block: matches, then (maximum depth, mean depth, redirections) after 0 / 1 / 2 / 4 / 12 rounds.
+Numbers of round 3: profiles/r3_linked_decode.txt."""
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, struct, bisect
 from oracle import ref
