@@ -7,12 +7,15 @@ import numpy as np, torch
 from skyplane_amd import hip_ops, synth
 n = int(os.environ.get("CHUNKS", "1024")); cb = synth.CHUNK_BYTES
 kind = os.environ.get("STREAM", "silesia")
-unit = synth.silesia_like(64 << 20, config_id=2) if kind == "silesia" else synth.mixed_chunks(8, cb, config_id=4).reshape(-1)
+if kind in synth.CLASSES:      # STREAM=<class>: 64 MiB of one class of the Silesia-like stream (what does each kind of data cost per block?)
+    unit = synth.gen_class(kind, 64 << 20, synth.rng_for(2, 77))
+else:
+    unit = synth.silesia_like(64 << 20, config_id=2) if kind == "silesia" else synth.mixed_chunks(8, cb, config_id=4).reshape(-1)
 d_unit = torch.from_numpy(unit).cuda()
 d_big = torch.zeros(n * cb + 8192, dtype=torch.uint8, device="cuda")      # slack on both sides: dev variants that read the block's neighbourhood from global memory
 d_in = d_big[4096:4096 + n * cb]
 for t in range(n * cb // unit.size):
-    d_in[t * unit.size:(t + 1) * unit.size] = torch.roll(d_unit, -((t * 7919 * 4096 + t * 13) % unit.size) if kind == "silesia" else 0)
+    d_in[t * unit.size:(t + 1) * unit.size] = torch.roll(d_unit, -((t * 7919 * 4096 + t * 13) % unit.size) if kind != "mixed" else 0)
 stride = (hip_ops.frame_bound(cb) + 255) & ~255
 d_out = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
 in_off = np.arange(n, dtype=np.uint64) * cb; in_len = np.full(n, cb, np.uint64)
