@@ -11,14 +11,18 @@
 #define LZ4S_BLOCK 65536u      // one LZ4 frame block (BD = 4), one workgroup
 #define LZ4S_SLICE 64u         // bytes parsed by one lane
 #define LZ4S_LANES 1024u       // lanes per workgroup = slices per block
+// Table shape.  Rounds 2-3 kept one candidate per 16 KiB REGION of the block (4096 buckets x 4 regions): four candidates per position, and waves whose
+// slices lie in the last region paid for four entries per row and up to four verifications per visit.  Round 4: ONE region, 16384 buckets -- the same
+// 64 KiB of LDS, one candidate per position.  On the model that costs 1.0 % of ratio on the Silesia-like stream (frames +1.6 % over the reference's
+// block-linked ones, every class within 9 %: scripts/dev/ratio_classes.py) and makes every wavefront as cheap as the first region's used to be.
 #ifndef LZ4S_RLOG
-#define LZ4S_RLOG 14           // log2 of a table region: candidates are kept per 16 KiB region of the block
+#define LZ4S_RLOG 16           // log2 of a table region (16 = the whole block)
 #endif
 #ifndef LZ4S_Q
-#define LZ4S_Q 4               // regions per block
+#define LZ4S_Q 1               // regions per block
 #endif
 #ifndef LZ4S_LOGB
-#define LZ4S_LOGB 12           // log2 buckets; table = buckets x Q entries of 4 bytes = 64 KiB
+#define LZ4S_LOGB 14           // log2 buckets; table = buckets x Q entries of 4 bytes = 64 KiB
 #endif
 #ifndef LZ4S_EXT
 #define LZ4S_EXT 256u          // a match may run this far past the end of its slice (overlaps are trimmed afterwards).  Measured again in round 3: 128 takes 1.0 % and 64
@@ -39,7 +43,9 @@
 #define LZ4S_TAGMASK 0x7FFFu   // 15-bit tags: an empty entry (tag bits 0xFFFF) can never look like a hit
 
 // hash of the five bytes at a position: g = little-endian dword, b4 = the byte after it
+#ifndef LZ4S_HASH
 #define LZ4S_HASH(g, b4) ((uint32_t)(g) * LZ4S_K1 + (uint32_t)(b4) * LZ4S_K3)
+#endif
 #define LZ4S_BUCKET(x) ((uint32_t)(x) >> (32 - LZ4S_LOGB))
 #define LZ4S_TAG(x) (((uint32_t)(x) >> (32 - LZ4S_LOGB - 15)) & LZ4S_TAGMASK)
 // table entry: tag in the high half so that min() keeps the EARLIEST position among equal tags; the position is
