@@ -37,17 +37,36 @@
                                // fewer insertions mean fewer evictions: the ratio on the Silesia-like stream is 0.3 % BETTER than with every position
                                // (step 4: 0.8 % worse), a match that starts on an odd position is found one byte later and moved back over the literal
 #endif
-#define LZ4S_K1 2654435761u
-#define LZ4S_K3 0x9E3779u      // 24-bit: the fifth byte goes through a full-rate 24-bit multiply-add on the GPU
-#define LZ4S_INF 0xFFFFFFFFu   // empty table entry
-#define LZ4S_TAGMASK 0x7FFFu   // 15-bit tags: an empty entry (tag bits 0xFFFF) can never look like a hit
-
-// hash of the five bytes at a position: g = little-endian dword, b4 = the byte after it
-#ifndef LZ4S_HASH
-#define LZ4S_HASH(g, b4) ((uint32_t)(g) * LZ4S_K1 + (uint32_t)(b4) * LZ4S_K3)
+// Hash of the five bytes at a position (round 4): two FULL-RATE 24-bit multiplies instead of a quarter-rate 32-bit one plus a byte mask --
+//   x = lo24(g0) * KA + lo24(g2) * KB   (mod 2^32),   g0 = little-endian dword at p, g2 = the dword at p + 2
+// lo24(g0) covers bytes p..p+2 and lo24(g2) bytes p+2..p+4; the kernel has both dwords anyway (g2 is position p + 2's g0) and v_mul_u32_u24 /
+// v_mad_u32_u24 ignore the top byte of their operands, so no masking instruction is needed.  The top 14 bits of x depend on all five bytes: bucket.
+// Bits 23..8 are the tag: whole bytes, so that "tag << 16 | position" is ONE v_perm_b32 (the six bits the tag shares with the bucket are dead weight; the
+// other ten -- and the low 16 bits, a hash of four bytes, would do worse: +0.3 % of frame bytes).  On the model every class compresses as well or better than
+// with the 32-bit multiply (scripts/dev/ratio_classes.py).
+#ifndef LZ4S_KA
+#define LZ4S_KA 0x9E3779u
 #endif
+#ifndef LZ4S_KB
+#define LZ4S_KB 0xC2B2AEu
+#endif
+#define LZ4S_INF 0xFFFFFFFFu   // empty table entry (tag 0xFFFF, position 0xFFFF: position 65535 never enters the table, so no hit can look like it)
+// Positions below this never enter the table (the block's first slice is nobody's candidate).  With every entry >= 64 the probe's test "same tag and
+// entry below position s0 + i" is  (entry - (tag << 16 | i)) < s0  -- the constant i folds into the v_perm_b32 that builds the tag word and no
+// per-position "s0 + i" is needed: one instruction per position saved for 64 of 65536 candidates.
+#define LZ4S_FIRST_INS 64u
+#define LZ4S_MUL24(a, b) ((uint32_t)((uint64_t)((uint32_t)(a) & 0xFFFFFFu) * (uint64_t)((uint32_t)(b) & 0xFFFFFFu)))
+#define LZ4S_HASH2(g0, g2) (LZ4S_MUL24(g0, LZ4S_KA) + LZ4S_MUL24(g2, LZ4S_KB))
+// the same from the dword at p and the byte after it (model, scalar callers)
+#ifndef LZ4S_HASH
+#define LZ4S_HASH(g, b4) LZ4S_HASH2(g, ((uint32_t)(g) >> 16) | ((uint32_t)(b4) << 16))
+#endif
+#ifndef LZ4S_BUCKET
 #define LZ4S_BUCKET(x) ((uint32_t)(x) >> (32 - LZ4S_LOGB))
-#define LZ4S_TAG(x) (((uint32_t)(x) >> (32 - LZ4S_LOGB - 15)) & LZ4S_TAGMASK)
+#endif
+#ifndef LZ4S_TAG
+#define LZ4S_TAG(x) (((uint32_t)(x) >> 8) & 0xFFFFu)
+#endif
 // table entry: tag in the high half so that min() keeps the EARLIEST position among equal tags; the position is
 // relative to its region
 #define LZ4S_ENTRY(tag, relpos) (((uint32_t)(tag) << 16) | (uint32_t)(relpos))

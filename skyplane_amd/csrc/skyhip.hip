@@ -32,7 +32,19 @@
 #define LZ4S_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 extern "C" __global__ void __launch_bounds__(LZ4S_LANES) LZ4S_KERNEL_ATTR sky_lz4s_compress(SkyLz4Args a) {
+    // The kernel's LDS (141 KiB, dynamic: a static array of that size would tell the register allocator that only four waves per SIMD fit and it would
+    // take 128 VGPRs) is addressed ABSOLUTELY, from LDS byte 16: the kernel has no other LDS, so the launch's dynamic segment starts at 0.  Through an
+    // `extern __shared__` array every one of the kernel's ~200 LDS address computations carried a `v_add_u32 v, <base>, v` for a base that is only
+    // known at link time.  (16, not 0: a literal 0 is the null pointer, which is -1 in the LDS address space.)
+#ifndef LZ4S_ABS_LDS
+#define LZ4S_ABS_LDS 1
+#endif
+#if LZ4S_ABS_LDS
+    typedef __attribute__((address_space(3))) uint8_t sky_lds_u8;
+    uint8_t* smem = (uint8_t*)(sky_lds_u8*)(uintptr_t)LZ4S_LDS_ORIGIN;
+#else
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#endif
     sky_lz4s_compress_body(a, smem);
 }
 #ifndef SKY_MD5_KERNEL_ATTR
@@ -316,7 +328,7 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
             HIPCHK(c, c->d_blk_word[k].ensure(nb));
             HIPCHK(c, c->d_blk_dst[k].ensure(nb));
         }
-        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_link, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4D_LINK_LDS));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
@@ -327,7 +339,7 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
 #endif
         if (getenv("SKYHIP_DEBUG")) {
             int nbs = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, (const void*)sky_lz4s_compress, LZ4S_LANES, LZ4S_LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, (const void*)sky_lz4s_compress, LZ4S_LANES, LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES);
             hipFuncAttributes fs;
             (void)hipFuncGetAttributes(&fs, (const void*)sky_lz4s_compress);
             fprintf(stderr, "[skyhip] sky_lz4s_compress: %d workgroups/CU (x16 waves), %d VGPRs, %u B dynamic LDS, grid %d\n", nbs, fs.numRegs, (unsigned)LZ4S_LDS_BYTES, c->lz4s_grid);
@@ -503,7 +515,7 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
                 if (sub >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, c->ev_fr_done[bf], 0));     // the frames of sub-batch sub-2 have left this buffer
                 HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4, c->s_lz4));     // block queue head
                 if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
-                hipLaunchKernelGGL(sky_lz4s_compress, dim3(nb < (uint32_t)c->lz4s_grid ? nb : (uint32_t)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_BYTES, c->s_lz4, la);
+                hipLaunchKernelGGL(sky_lz4s_compress, dim3(nb < (uint32_t)c->lz4s_grid ? nb : (uint32_t)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES, c->s_lz4, la);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
                 c->tm.lz4_launches++; c->tm.lz4_in_bytes += sub_bytes;

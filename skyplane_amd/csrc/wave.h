@@ -119,6 +119,23 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+// full-rate 24-bit integer multiply(-add): v_mul_u32_u24 / v_mad_u32_u24 use the low 24 bits of a and b and return the low 32 bits of the product
+// (a 32-bit v_mul_lo_u32 issues at a quarter of that rate)
+SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+// v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {hi, lo} (0-3 = lo's bytes, 4-7 = hi's, 0x0c = 0x00)
+SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// bits = 2 * bits + (a < b)  /  + (a == b): a compare into VCC and v_addc_co_u32 bits, bits, bits, vcc -- two VALU instructions per position and no
+// scalar ones, where a compare + select + or costs three and building the union of two conditions an s_or_b64 on top (the scalar unit is the
+// compressor's second-busiest, profiles/r3_pmc_lz4s.txt).  Collecting a lane's bit mask this way fills it from the top: callers walk positions downwards.
+SKY_DEV uint32_t sky_shl1_lt(uint32_t bits, uint32_t a, uint32_t b) {
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    return bits;
+}
+SKY_DEV uint32_t sky_shl1_eq(uint32_t bits, uint32_t a, uint32_t b) {
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    return bits;
+}
 // keep a prefetched value alive up to this point (the load warms L2/L1 for a later batch; nothing reads it)
 // returns v, but the compiler may assume nothing about the result (stops CSE / hoisting across this point)
 SKY_DEV uint32_t sky_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }

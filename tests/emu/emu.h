@@ -73,6 +73,20 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return *p; }
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return (uint32_t)((sky_u64)(a & 0xFFFFFFu) * (sky_u64)(b & 0xFFFFFFu)); }
+SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return sky_mul24(a, b) + c; }
+SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) {      // v_perm_b32 (selectors 0-7 and 0x0c only: what the kernels use)
+    const sky_u64 both = ((sky_u64)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t sl = (sel >> (8 * k)) & 0xFFu;
+        const uint32_t b = sl < 8u ? (uint32_t)(both >> (8 * sl)) & 0xFFu : (sl == 0x0cu ? 0u : 0xFFu);
+        r |= b << (8 * k);
+    }
+    return r;
+}
+SKY_DEV uint32_t sky_shl1_lt(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a < b ? 1u : 0u); }
+SKY_DEV uint32_t sky_shl1_eq(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a == b ? 1u : 0u); }
 SKY_DEV void sky_keep(uint32_t) {}
 SKY_DEV uint32_t sky_opaque(uint32_t v) { return v; }
 #define SKY_RESTRICT

@@ -46,8 +46,8 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
     memset(T, 0xFF, (size_t)NB * LZ4S_Q * 4);
     if (n >= 13u) {
         const uint32_t mflimit = n - 12u, matchlimit = n - 5u;
-        // pre-pass: earliest position per (bucket, region) among equal tags; every LZ4S_INS_STEP-th position is entered
-        for (uint32_t p = 0; p <= mflimit; p += LZ4S_INS_STEP) {
+        // pre-pass: earliest position per (bucket, region) among equal tags; every LZ4S_INS_STEP-th position from LZ4S_FIRST_INS on is entered
+        for (uint32_t p = LZ4S_FIRST_INS; p <= mflimit; p += LZ4S_INS_STEP) {
             const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
             uint32_t* e = &T[LZ4S_BUCKET(x) * LZ4S_Q + (p >> LZ4S_RLOG)];
             const uint32_t v = LZ4S_ENTRY(LZ4S_TAG(x), p & ((1u << LZ4S_RLOG) - 1u));
