@@ -93,6 +93,12 @@ SKY_DEV uint32_t sky_scan_incl_max(uint32_t x) {
     return x;
 }
 SKY_DEV uint32_t sky_wave_max_u32(uint32_t x) { return sky_readlane(sky_scan_incl_max(x), 63); }
+// the value of the lane before (0 in lane 0): one DPP move across the whole wavefront (wave_shr:1), no LDS round trip
+SKY_DEV uint32_t sky_wave_shr1(uint32_t x) {
+    uint32_t r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0" : "=&v"(r) : "v"(x));
+    return r;
+}
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t x) {
     const int lane = sky_lane();
     for (int d = 1; d < 64; d <<= 1) {

@@ -51,6 +51,7 @@ SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV uint32_t sky_scan_incl_max(uint32_t v) { return (uint32_t)emu_collective(EMU_SCANMAX, v, 0); }
 SKY_DEV uint32_t sky_wave_max_u32(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, emu_collective(EMU_SCANMAX, v, 0), 63); }
+SKY_DEV uint32_t sky_wave_shr1(uint32_t v) { const uint32_t t = (uint32_t)emu_collective(EMU_SHFL, v, (sky_u64)((sky_lane() - 1) & 63)); return sky_lane() ? t : 0u; }
 SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV void sky_sched_fence() {}
 template <int P> SKY_DEV void sky_setprio() {}
