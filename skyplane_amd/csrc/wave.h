@@ -115,6 +115,7 @@ SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { return __hip_atomic_
 // flags in LDS that one wavefront of a workgroup stores and the others poll (sky_lz4_link): a real ds_read per poll; sky_wave_yield gives the SIMD to the
 // wavefronts that are being waited for
 SKY_DEV uint32_t sky_lds_poll_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SKY_DEV sky_u64 sky_lds_poll_u64(const sky_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV void sky_wave_yield() { __builtin_amdgcn_s_sleep(1); }
 // compiler-only ordering of this wavefront's LDS accesses: the DS queue of a wavefront is served in order, so a load issued after a store sees it and a
 // flag stored after data is seen after it -- nothing to wait for (sky_wave_fence costs an s_waitcnt lgkmcnt(0))
