@@ -227,6 +227,7 @@ def main():
                     if idx:
                         wire[k] += n_sent
                     trace["sent"].append(time.perf_counter())
+                hip_sender.drain_releases(sock)         # slots go back when the peer has acknowledged their bytes, not when sendfile returns
 
         def wait_decoded(n):
             got = 0

@@ -97,22 +97,41 @@ def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
     return Recipe(lane=lane, epoch=epoch, raw_len=raw_len, lit_raw_len=lit_raw, segs=segs, lit_frame=mv[HEADER_BYTES + SEG_BYTES * nseg:])
 
 
+class StoreEvicted(RecipeError):
+    """A reference names a (lane, epoch) group that the destination's byte budget evicted: retrying cannot help."""
+
+
 class _Bounds:
     """What keeps a segment store finite, shared by both stores.  (lane, epoch) groups are dropped
       * when a newer epoch of the same lane shows up (``keep_epochs``, as before) -- checked only when a lane's highest epoch actually grows;
       * least recently used first when the store holds more than ``max_bytes`` (the group being written is never the victim);
       * when nothing has touched them for ``idle_s`` seconds (a transfer that ended: its lanes never send a newer epoch).
     An epoch that jumps more than ``max_epoch_jump`` ahead of what a known lane has reached is refused: the number comes from an untrusted payload,
-    and honouring it would retire every live epoch of that lane."""
+    and honouring it would retire every live epoch of that lane.
+    LIVE groups -- within ``keep_epochs`` of their lane's highest epoch, of a lane that was used in the last ``live_grace_s`` seconds -- are what the sender
+    may still reference: the byte budget never evicts them (the sender is not told, the chunk would park and then fail); the store then runs over
+    its budget (``over_budget_live``) -- bounded by lanes x keep_epochs x the sender's epoch size -- and the operator says so once.  A live-looking group
+    of a lane that has been silent for longer may go, and is remembered: a later reference to it fails at once with StoreEvicted instead of waiting."""
 
-    def __init__(self, keep_epochs, max_bytes, idle_s, max_epoch_jump):
+    def __init__(self, keep_epochs, max_bytes, idle_s, max_epoch_jump, live_grace_s=30.0):
         self.keep_epochs = max(1, int(keep_epochs))
         self.max_bytes = int(max_bytes)
         self.idle_s = float(idle_s)
         self.max_epoch_jump = int(max_epoch_jump)
+        self.live_grace_s = float(live_grace_s)
         self.lane_max: Dict[int, int] = {}
         self.touched: Dict[Tuple[int, int], float] = {}
         self.nbytes: Dict[Tuple[int, int], int] = {}
+        self.evicted: Dict[Tuple[int, int], float] = {}      # groups the byte budget took although their lane had not moved on (bounded: see over_budget)
+        self.over_budget_live = False
+
+    def is_live(self, key, now=None) -> bool:
+        top = self.lane_max.get(key[0])
+        if top is None or key[1] + self.keep_epochs <= top:
+            return False
+        now = time.monotonic() if now is None else now
+        lane_touch = max((t for k, t in self.touched.items() if k[0] == key[0]), default=0.0)
+        return now - lane_touch <= self.live_grace_s
 
     def admit(self, lane: int, epoch: int) -> List[Tuple[int, int]]:
         """Called (under the store's lock) before (lane, epoch) is written; returns the groups to drop because of it."""
@@ -131,14 +150,26 @@ class _Bounds:
         return drop
 
     def over_budget(self, keep: Tuple[int, int]) -> List[Tuple[int, int]]:
-        total, drop = sum(self.nbytes.values()), []
+        total, drop, now = sum(self.nbytes.values()), [], time.monotonic()
         for k in sorted(self.touched, key=self.touched.get):
             if total <= self.max_bytes:
                 break
-            if k != keep:
-                drop.append(k)
-                total -= self.nbytes.get(k, 0)
+            if k == keep or self.is_live(k, now):
+                continue
+            drop.append(k)
+            total -= self.nbytes.get(k, 0)
+            top = self.lane_max.get(k[0])
+            if top is not None and k[1] + self.keep_epochs > top:      # the lane never moved past it: somebody may still ask for it
+                if len(self.evicted) >= 4096:
+                    self.evicted.pop(next(iter(self.evicted)))
+                self.evicted[k] = now
+        self.over_budget_live = total > self.max_bytes
         return drop
+
+    def check_not_evicted(self, lane: int, epoch: int):
+        if (lane, epoch) in self.evicted:
+            raise StoreEvicted(f"segments of lane {lane:#x} epoch {epoch} were evicted by the destination's byte budget ({self.max_bytes} bytes): "
+                               "raise the segment store's max_bytes or lower the sender's dedup_epoch_bytes")
 
     def forget(self, key):
         self.touched.pop(key, None)
@@ -155,11 +186,15 @@ class SegmentStore:
     (that object, offset, length): no per-segment copies, and neighbouring segments stay neighbours, so a run of references into one earlier chunk
     is rebuilt with one copy."""
 
-    def __init__(self, keep_epochs: int = 2, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2):
+    def __init__(self, keep_epochs: int = 2, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2, live_grace_s: float = 30.0):
         self.keep_epochs = max(1, int(keep_epochs))
-        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump)
+        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump, live_grace_s)
         self._lock = threading.Lock()
         self._segs: Dict[Tuple[int, int], Dict[bytes, Tuple[bytes, int, int]]] = {}
+
+    @property
+    def over_budget_live(self) -> bool:
+        return self._b.over_budget_live
 
     @property
     def bytes_held(self) -> int:
@@ -190,6 +225,7 @@ class SegmentStore:
 
     def get_many(self, lane: int, epoch: int, fps: List[bytes]) -> List[Optional[Tuple[bytes, int, int]]]:
         with self._lock:
+            self._b.check_not_evicted(lane, epoch)
             d = self._segs.get((lane, epoch), {})
             if d:
                 self._b.touched[(lane, epoch)] = time.monotonic()
@@ -217,12 +253,13 @@ class FileSegmentStore:
 
     _REC = struct.Struct("<16sII16s")
 
-    def __init__(self, directory, keep_epochs: int = 2, max_maps: int = 256, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2):
+    def __init__(self, directory, keep_epochs: int = 2, max_maps: int = 256, max_bytes: int = 4 << 30, idle_s: float = 600.0, max_epoch_jump: int = 2,
+                 live_grace_s: float = 30.0):
         self.dir = Path(directory)
         self.dir.mkdir(parents=True, exist_ok=True)
         self.keep_epochs = max(1, int(keep_epochs))
         self.max_maps = max_maps
-        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump)      # this process's view: what IT wrote or read (every worker bounds its share)
+        self._b = _Bounds(keep_epochs, max_bytes, idle_s, max_epoch_jump, live_grace_s)      # this process's view: what IT wrote or read (every worker bounds its share)
         self._lock = threading.Lock()
         self._idx: Dict[Tuple[int, int], Tuple[Dict[bytes, Tuple[bytes, int, int]], int]] = {}     # (lane, epoch) -> (fp -> (stream id, off, len), bytes of the index read)
         self._maps: Dict[bytes, mmap.mmap] = {}
@@ -257,26 +294,49 @@ class FileSegmentStore:
                 old.add((lane, e))
         self._drop(old)
 
+    @property
+    def over_budget_live(self) -> bool:
+        return self._b.over_budget_live
+
+    def _group_idle(self, key, now_wall: float) -> bool:
+        """Idle for EVERY worker?  Appends by any process move the index file's mtime; this process's own clock only knows its own accesses."""
+        try:
+            return now_wall - self._index_path(*key).stat().st_mtime > self._b.idle_s
+        except FileNotFoundError:
+            return True
+
     def put_chunk(self, lane: int, epoch: int, fps: List[bytes], offs, lens, litbuf: bytes):
+        with self._lock:
+            top = self._b.lane_max.get(lane)
+            if top is None or epoch > top:
+                # My view of the lane may be stale: the workers of a destination share the lane's chunks, and the others may have carried it
+                # several epochs further while this one saw none of them (ADVICE r3: worker A puts epoch 0, B puts 1 and 2, A's epoch 3 was
+                # refused as a jump from 0).  The directory is the shared truth: one scan, only when the lane grows in this process's eyes.
+                held = self.epochs_held(lane)
+                if held and (top is None or held[-1] > top):
+                    self._b.lane_max[lane] = top = held[-1]
+            grew = top is None or epoch > top
+            drop = self._b.admit(lane, epoch)              # raises on an epoch far ahead of the lane -- BEFORE anything is written: no orphan stream file
+            now_wall = time.time()
+            drop = [k for k in drop if k[0] == lane and k[1] + self.keep_epochs <= epoch or self._group_idle(k, now_wall)]   # retired, or idle for everybody
+            if grew:
+                self._retire_older(lane, epoch)
+            self._drop(drop)
         sid = os.urandom(16)
         final = self._stream_path(lane, epoch, sid)
         tmp = final.with_suffix(".tmp")
         tmp.write_bytes(litbuf)
         os.replace(tmp, final)                            # a record never names a stream that is not complete
         recs = b"".join(self._REC.pack(fp, int(o), int(n), sid) for fp, o, n in zip(fps, offs, lens))
-        with self._lock:
-            grew = self._b.lane_max.get(lane) is None or epoch > self._b.lane_max[lane]
-            drop = self._b.admit(lane, epoch)              # (raises on an epoch far ahead of the lane: the stream file below is then an orphan of a bad payload)
-            if grew:
-                self._retire_older(lane, epoch)
-            self._drop(drop)
-            self._b.nbytes[(lane, epoch)] += len(litbuf)
-            self._drop(self._b.over_budget((lane, epoch)))
         with open(self._index_path(lane, epoch), "ab") as f:
             fcntl.flock(f, fcntl.LOCK_EX)
             f.write(recs)
             f.flush()
             fcntl.flock(f, fcntl.LOCK_UN)
+        with self._lock:
+            if (lane, epoch) in self._b.nbytes:
+                self._b.nbytes[(lane, epoch)] += len(litbuf)
+            self._drop(self._b.over_budget((lane, epoch)))      # never a live group (_Bounds.is_live): other workers still index those files
 
     def _refresh(self, lane: int, epoch: int):
         d, pos = self._idx.get((lane, epoch), ({}, 0))
@@ -309,6 +369,7 @@ class FileSegmentStore:
 
     def get_many(self, lane: int, epoch: int, fps: List[bytes]):
         with self._lock:
+            self._b.check_not_evicted(lane, epoch)
             d = self._idx.get((lane, epoch), ({}, 0))[0]
             if any(fp not in d for fp in fps):
                 d = self._refresh(lane, epoch)

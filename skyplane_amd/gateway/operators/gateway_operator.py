@@ -143,7 +143,8 @@ class GatewayHipCompress(GatewayOperator):
                  chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: Optional[float] = None,
-                 prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0):
+                 prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0,
+                 arena_slot_bytes: int = 0):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
         # How a frame reaches the sender.  "arena": the device writes it by DMA into a slot of a shared, page-locked arena file in
         # the chunk directory and `<id>.chunk.lz4f` is a pointer to the slot (gateway/shm_arena.py) -- the sender sendfile()s it from there and unlinks
@@ -152,6 +153,10 @@ class GatewayHipCompress(GatewayOperator):
         assert handoff in ("arena", "files")
         self.handoff = handoff
         self.arena_slots = int(arena_slots)
+        # bytes per arena slot: 0 = the frame bound of the largest chunk of the lane's FIRST batch (an arena is page-locked as a whole: sized for the
+        # 64 MiB default chunk it was 4 GiB of pinned tmpfs per lane even when the transfer's chunks are 8 MiB -- ADVICE r3); a later, larger chunk goes
+        # out as a plain payload file
+        self.arena_slot_bytes = int(arena_slot_bytes)
         # dedup on the wire (skyplane_amd/gateway/dedup_wire.py): every chunk leaves as a recipe -- literal segments, LZ4-compressed, plus references to
         # segments this lane sent before -- instead of as one LZ4 frame.  Needs gpu_decompress(dedup_wire=True) on the destination gateway.
         self.dedup_wire = bool(dedup_wire)
@@ -230,11 +235,13 @@ class GatewayHipCompress(GatewayOperator):
             self._arenas[which] = cur
         return cur
 
-    def _writer(self, ctx) -> "shm_arena.ArenaWriter":
-        """This lane's arena (created on first use, page-locked through the lane's context when that is a real device)."""
+    def _writer(self, ctx, largest: int = 0) -> "shm_arena.ArenaWriter":
+        """This lane's arena (created on first use, page-locked through the lane's context when that is a real device).  `largest` = the largest chunk of
+        the batch at hand: it sizes the slots when arena_slot_bytes was left at 0."""
         w = getattr(self._tls, "writer", None)
         if w is None:
-            bound = ctx.frame_bound(self.max_chunk_bytes) if hasattr(ctx, "frame_bound") else 15 + self.max_chunk_bytes + 4 * ((self.max_chunk_bytes + 65535) // 65536) + 4
+            fb = ctx.frame_bound if hasattr(ctx, "frame_bound") else (lambda n: 15 + n + 4 * ((n + 65535) // 65536) + 4)
+            bound = self.arena_slot_bytes or (fb(min(max(largest, 1 << 16), self.max_chunk_bytes)) + 4095) & ~4095
             tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
             w = shm_arena.ArenaWriter(self.chunk_store.get_chunk_file_path("x").parent, tag, bound, self.arena_slots or 2 * self.max_batch)
             shm_arena.register_once(w.arena, ctx)
@@ -274,8 +281,10 @@ class GatewayHipCompress(GatewayOperator):
         ctx = self._context()
         datas = self._read_chunks(chunk_reqs, ctx)
         # frames that go out as they are (no recipes) are produced straight into arena slots when there are free ones
-        writer = self._writer(ctx) if (self.handoff == "arena" and not self.dedup_wire) else None
-        slots = writer.take(len(datas)) if writer is not None else []
+        writer = self._writer(ctx, max((len(d) for d in datas), default=0)) if (self.handoff == "arena" and not self.dedup_wire) else None
+        fits = writer is not None and all((ctx.frame_bound(len(d)) if hasattr(ctx, "frame_bound") else len(d) + len(d) // 255 + 64) <= writer.arena.slot_bytes for d in datas)
+        slots = writer.take(len(datas)) if fits else []
+        published = 0
         try:
             if hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound"):
                 bounds = [ctx.frame_bound(len(d)) for d in datas]
@@ -296,25 +305,31 @@ class GatewayHipCompress(GatewayOperator):
             raise
         recipes = self._build_recipes(ctx, datas, results) if self.dedup_wire else None
         self._last_metadata = []
-        for k, (cr, data, res) in enumerate(zip(chunk_reqs, datas, results)):
-            cid = cr.chunk.chunk_id
-            payload = recipes[k][0] if recipes is not None else res.frame
-            if k < len(slots):
-                writer.publish(slots[k], sidecar.compressed_path(self.chunk_store, cid), len(payload))      # pointer file: complete when visible
-            else:
-                tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
-                with open(tmp, "wb") as f:
-                    f.write(payload)
-                os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
-            meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": len(data)}
-            if recipes is not None:
-                meta["dedup_reference_bytes"] = recipes[k][1]
-            if res.md5 is not None:
-                sidecar.digest_path(self.chunk_store, cid).write_text(res.md5.hex())
-                meta["md5_hex"] = res.md5.hex()
-            if res.cuts is not None:
-                meta["cdc_segments"] = int(len(res.cuts))
-            self._last_metadata.append(meta)
+        try:
+            for k, (cr, data, res) in enumerate(zip(chunk_reqs, datas, results)):
+                cid = cr.chunk.chunk_id
+                payload = recipes[k][0] if recipes is not None else res.frame
+                if k < len(slots):
+                    writer.publish(slots[k], sidecar.compressed_path(self.chunk_store, cid), len(payload))      # pointer file: complete when visible
+                    published = k + 1
+                else:
+                    tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
+                    with open(tmp, "wb") as f:
+                        f.write(payload)
+                    os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
+                meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": len(data)}
+                if recipes is not None:
+                    meta["dedup_reference_bytes"] = recipes[k][1]
+                if res.md5 is not None:
+                    sidecar.digest_path(self.chunk_store, cid).write_text(res.md5.hex())
+                    meta["md5_hex"] = res.md5.hex()
+                if res.cuts is not None:
+                    meta["cdc_segments"] = int(len(res.cuts))
+                self._last_metadata.append(meta)
+        except BaseException:
+            for sl in slots[published:]:          # slots taken for this batch and never published would stay busy for ever
+                writer.give_back(sl)
+            raise
         return [True] * len(chunk_reqs)
 
     def _build_recipes(self, ctx, datas, results):
@@ -416,7 +431,7 @@ class GatewayHipCompress(GatewayOperator):
                 continue
             self._arena(ctx, which, per * self.max_batch)[::4096] = 0
         if self.handoff == "arena" and not self.dedup_wire and not decomp:
-            self._writer(ctx)
+            self._writer(ctx, self.max_chunk_bytes)      # prealloc: the configured maximum sizes the slots
 
     def _lane_loop(self, worker_id: int):
         """One pipeline lane: drain up to max_batch requests, one device call, hand the chunks on."""
@@ -440,6 +455,7 @@ class GatewayHipCompress(GatewayOperator):
                 for cr, ok, meta in zip(batch, oks, self._last_metadata):
                     if ok:
                         self.chunk_store.log_chunk_state(cr, ChunkState.complete, operator_handle=self.handle, worker_id=worker_id, metadata=meta)
+                        getattr(self._tls, "tries", {}).pop(cr.chunk.chunk_id, None)      # (its back-off history goes with it: the dict must not grow with the transfer)
                         if self.output_queue is not None:
                             self.output_queue.put(cr)
                     else:
@@ -455,6 +471,7 @@ class GatewayHipCompress(GatewayOperator):
         for _due, _n, cr in self._parked():           # what still waits goes back to the queue: another worker (or a restart) may finish it
             self.input_queue.put(cr)
         self._parked().clear()
+        getattr(self._tls, "tries", {}).clear()
         self.worker_exit(worker_id)                    # this lane's context and arenas (thread-local)
 
     def worker_loop(self, worker_id: int, *args):

@@ -5,8 +5,13 @@ replacement for those lines: ship the pre-compressed sidecar when present, other
 the receiver (gateway_receiver.py:142-237) and chunk.py stay untouched.  INTEGRATION.md shows the ~10-line patch."""
 from __future__ import annotations
 
+import array
+import fcntl
 import os
-from typing import Optional, Tuple
+import termios
+import time
+from collections import deque
+from typing import Dict, Optional, Tuple
 
 from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
 from skyplane_amd.gateway import shm_arena, sidecar
@@ -27,6 +32,62 @@ def wire_payload(chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left
     return header, data
 
 
+# ---- when may an arena slot be handed back? ----------------------------------------------------------------------------------------------------
+# os.sendfile() from a tmpfs mapping is zero-copy: when it returns, the socket's send queue REFERENCES the arena's pages -- for the data that has
+# not left yet and for whatever TCP may still have to retransmit (sendfile(2): the file must stay unmodified until the peer has the data).  Unlinking
+# the pointer file at that moment (round 3 did) lets gpu_compress DMA the next frame into the slot while the old frame's tail is still queued: silent
+# corruption of the wire payload under a real RTT, and our frames carry no checksum.  So a released frame is only NOTED here with the socket's running
+# byte count, and its pointer is unlinked when the kernel says that many bytes have been acknowledged (SIOCOUTQ = unacknowledged bytes of the send queue).
+class _SockLedger:
+    __slots__ = ("sent", "pending")
+
+    def __init__(self):
+        self.sent = 0                  # bytes handed to this socket by send_chunk so far
+        self.pending = deque()         # (byte count at the end of the frame, pointer path) in send order
+
+
+_LEDGERS: Dict[int, _SockLedger] = {}
+
+
+def _unacked(sock) -> int:
+    buf = array.array("i", [0])
+    fcntl.ioctl(sock.fileno(), termios.TIOCOUTQ, buf)       # SIOCOUTQ on a TCP socket: bytes written and not yet acknowledged by the peer
+    return int(buf[0])
+
+
+def _unlink_quiet(path):
+    try:
+        path.unlink()
+    except FileNotFoundError:
+        pass
+
+
+def release_acked(sock) -> int:
+    """Unlink the pointer files of this socket's released frames whose bytes the peer has acknowledged; returns how many are still waiting."""
+    led = _LEDGERS.get(sock.fileno())
+    if led is None or not led.pending:
+        return 0
+    try:
+        acked = led.sent - _unacked(sock)
+    except OSError:                        # not a TCP socket (a test's socketpair): nothing is ever retransmitted, delivered = copied
+        acked = led.sent
+    while led.pending and led.pending[0][0] <= acked:
+        _unlink_quiet(led.pending.popleft()[1])
+    return len(led.pending)
+
+
+def drain_releases(sock, timeout: float = 30.0) -> None:
+    """Call before closing a socket that sent frames with ``release=True``: waits (bounded) until the peer has acknowledged everything, then frees
+    the slots; on timeout the pointers stay -- a slot that is never freed costs capacity, a slot freed too early costs correctness."""
+    end = time.monotonic() + timeout
+    while release_acked(sock):
+        if time.monotonic() > end:
+            break
+        time.sleep(0.0005)
+    if not (_LEDGERS.get(sock.fileno()) or _SockLedger()).pending:
+        _LEDGERS.pop(sock.fileno(), None)
+
+
 def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int, release: bool = False) -> int:
     """Header + payload of one chunk, the payload straight from its file to the socket (``socket.sendfile`` -> os.sendfile on a plain TCP
     socket): the same bytes ``wire_payload`` + ``sendall`` put on the wire without the copy through a Python ``bytes`` -- the frame was
@@ -37,18 +98,19 @@ def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_
     compressed = frame_path.exists()
     if compressed:
         # the frame lives in a payload file or -- gpu_compress(handoff="arena") -- in a slot of the shared arena that `<id>.chunk.lz4f` points to:
-        # either way its pages go to the socket by sendfile; `release` unlinks the sidecar afterwards, which is what frees an arena slot
+        # either way its pages go to the socket by sendfile; `release` frees the sidecar (= the arena slot) once the peer has acknowledged the bytes
+        # (release_acked / drain_releases above), never at sendfile's return
         size = shm_arena.open_payload(frame_path).length
         header = chunk.to_wire_header(n_chunks_left_on_socket=n_chunks_left_on_socket, wire_length=size, raw_wire_length=chunk.chunk_length_bytes, is_compressed=True)
         header.to_socket(sock)
         sent = shm_arena.sendfile_payload(sock, frame_path)
         if sent != size:
             raise ConnectionError(f"chunk {chunk.chunk_id}: {sent} of {size} payload bytes sent")
+        led = _LEDGERS.setdefault(sock.fileno(), _SockLedger())
+        led.sent += len(header.to_bytes()) + size
         if release:
-            try:
-                frame_path.unlink()
-            except FileNotFoundError:
-                pass
+            led.pending.append((led.sent, frame_path))
+        release_acked(sock)
         return size
     path = chunk_store.get_chunk_file_path(chunk.chunk_id)
     with open(path, "rb") as f:

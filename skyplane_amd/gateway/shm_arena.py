@@ -20,6 +20,8 @@ from __future__ import annotations
 
 import mmap
 import os
+import socket
+import time
 import struct
 import threading
 from pathlib import Path
@@ -266,6 +268,7 @@ def sendfile_payload(sock, path) -> int:
         sock.sendall(p.view)
         return p.length
     tmo = sock.gettimeout()
+    deadline = None if tmo is None else time.monotonic() + tmo      # the socket's timeout bounds every wait for buffer space, like sock.sendall
     while sent < p.length:
         try:
             n = os.sendfile(fd_out, p.arena.fd, p.off + sent, p.length - sent)
@@ -274,8 +277,12 @@ def sendfile_payload(sock, path) -> int:
                 raise
             import select
 
-            select.select([], [fd_out], [], tmo)
+            left = None if deadline is None else deadline - time.monotonic()
+            if left is not None and left <= 0 or not select.select([], [fd_out], [], left)[1]:
+                raise socket.timeout(f"timed out after {sent} of {p.length} payload bytes")       # a stalled peer: do not spin for ever
             continue
+        if deadline is not None:
+            deadline = time.monotonic() + tmo
         if n == 0:
             raise ConnectionError(f"socket closed after {sent} of {p.length} payload bytes")
         sent += n

@@ -467,13 +467,15 @@ def test_waiting_recipe_stores_its_literals_once_and_is_not_decoded_again(tmp_pa
 
 
 def test_segment_stores_are_bounded_and_distrust_epochs(tmp_path):
-    for store in (dedup_wire.SegmentStore(max_bytes=3000, idle_s=0), dedup_wire.FileSegmentStore(tmp_path / "seg", max_bytes=3000, idle_s=0)):
+    for store in (dedup_wire.SegmentStore(max_bytes=3000, idle_s=0, live_grace_s=0), dedup_wire.FileSegmentStore(tmp_path / "seg", max_bytes=3000, idle_s=0, live_grace_s=0)):
         fp = lambda k: bytes([k]) * 16      # noqa: E731
-        for lane in (1, 2, 3, 4):           # 1000 bytes per lane: the fourth pushes the least recently used lane out
+        for lane in (1, 2, 3, 4):           # 1000 bytes per lane, lanes long silent (grace 0): the fourth pushes the least recently used lane out
             store.put_chunk(lane, 0, [fp(lane)], [0], [1000], bytes([lane]) * 1000)
             if lane == 2:
                 assert store.get(1, 0, fp(1)) is not None       # touch lane 1: lane 2 is the oldest from now on
-        assert store.get(2, 0, fp(2)) is None and store.get(1, 0, fp(1)) == b"\x01" * 1000 and store.get(4, 0, fp(4)) is not None
+        with pytest.raises(dedup_wire.StoreEvicted):            # ... and a reference to what the budget took fails at once, it does not wait
+            store.get(2, 0, fp(2))
+        assert store.get(1, 0, fp(1)) == b"\x01" * 1000 and store.get(4, 0, fp(4)) is not None
         # a known lane that claims an epoch far ahead is refused (it would retire everything the lane holds); a small step is normal
         with pytest.raises(dedup_wire.RecipeError):
             store.put_chunk(1, 0xFFFFFFFF, [fp(9)], [0], [10], b"x" * 10)
@@ -493,6 +495,31 @@ def test_segment_stores_are_bounded_and_distrust_epochs(tmp_path):
     for p in (tmp_path / "seg2").glob("*.lit"):
         p.unlink()
     assert f.get_many(5, 0, [b"c" * 16]) == [None]
+
+
+def test_live_epochs_survive_the_byte_budget_and_workers_share_a_lanes_epoch(tmp_path):
+    """ADVICE r3.  (a) The byte budget never evicts what a sender may still reference: groups within keep_epochs of the top of a lane that is in use.
+    (b) Several destination workers share one FileSegmentStore directory: a worker that saw none of a lane's chunks for a few epochs must not take the
+    next one for a forged jump."""
+    fp = lambda k: bytes([k]) * 16      # noqa: E731
+    for store in (dedup_wire.SegmentStore(max_bytes=3000), dedup_wire.FileSegmentStore(tmp_path / "live", max_bytes=3000)):
+        for lane in (1, 2, 3, 4):
+            store.put_chunk(lane, 0, [fp(lane)], [0], [1000], bytes([lane]) * 1000)
+        assert all(store.get(lane, 0, fp(lane)) == bytes([lane]) * 1000 for lane in (1, 2, 3, 4)) and store.over_budget_live
+        store.put_chunk(1, 1, [fp(5)], [0], [1000], b"e" * 1000)                       # epoch 0 of lane 1 is still live (keep_epochs = 2)
+        assert store.get(1, 0, fp(1)) is not None and store.get(1, 1, fp(5)) is not None
+        store.put_chunk(1, 2, [fp(6)], [0], [1000], b"f" * 1000)                       # ... and retired when the lane reaches epoch 2
+        assert store.get(1, 0, fp(1)) is None and store.epochs_held(1) == [1, 2]
+        store.cleanup()
+    a, b = dedup_wire.FileSegmentStore(tmp_path / "shared"), dedup_wire.FileSegmentStore(tmp_path / "shared")
+    a.put_chunk(7, 0, [fp(1)], [0], [4], b"aaaa")
+    b.put_chunk(7, 1, [fp(2)], [0], [4], b"bbbb")
+    b.put_chunk(7, 2, [fp(3)], [0], [4], b"cccc")
+    a.put_chunk(7, 3, [fp(4)], [0], [4], b"dddd")                                       # used to raise: "lane 0x7 jumps from epoch 0 to 3"
+    assert a.get(7, 3, fp(4)) == b"dddd" and b.get(7, 3, fp(4)) == b"dddd" and a.get(7, 2, fp(3)) == b"cccc"
+    with pytest.raises(dedup_wire.RecipeError):
+        a.put_chunk(7, 40, [fp(9)], [0], [4], b"eeee")                                  # a real jump is still refused ...
+    assert not list((tmp_path / "shared").glob("L*-40-*"))                              # ... and leaves no orphan stream file behind
 
 
 def test_not_ready_chunks_wait_with_backoff_inside_the_lane(tmp_path):

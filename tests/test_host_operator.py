@@ -217,13 +217,19 @@ def test_operator_shared_arena_handoff(tmp_path, monkeypatch):
         hdr, payload = hip_sender.wire_payload(store, cr, n_chunks_left_on_socket=0)
         assert hdr.is_compressed and hdr.data_len == len(payload) and ref.lz4f_decompress(payload, len(data)) == data
     assert kinds == [True] * 5 + [False]                                         # five slots, the sixth chunk fell back to a payload file
-    # the sender: slot pages -> socket; release=True unlinks the pointer and the slot can be taken again
+    # the sender: slot pages -> socket.  release=True frees the slot only when the peer HAS the bytes: sendfile is zero-copy, the socket's queue still
+    # references the arena's pages when it returns (round 3 unlinked the pointer right away)
     a, b = socket.socketpair()
+    a.setsockopt(socket.SOL_SOCKET, socket.SO_SNDBUF, 1 << 20)
     got = bytearray()
+    sent = hip_sender.send_chunk(a, store, crs[0], n_chunks_left_on_socket=0, release=True)
+    ptr = store.get_compressed_file_path(crs[0].chunk.chunk_id)
+    assert ptr.exists() and hip_sender.release_acked(a) == 1                     # nothing read yet on the other end: the slot stays taken
     import threading
     rd = threading.Thread(target=lambda: [got.extend(x) for x in iter(lambda: b.recv(1 << 16), b"")])
     rd.start()
-    sent = hip_sender.send_chunk(a, store, crs[0], n_chunks_left_on_socket=0, release=True)
+    hip_sender.drain_releases(a, timeout=10.0)
+    assert not ptr.exists()
     a.close(); rd.join(); b.close()
     h = WireProtocolHeader.from_bytes(bytes(got[:53]))
     assert h.is_compressed and h.data_len == sent == len(got) - 53 and ref.lz4f_decompress(bytes(got[53:]), 70_001) == reqs[0][1]
