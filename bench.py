@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--verify", choices=["full", "sample", "none"], default="full", help="post-run check of digests (all / 64 chunks) and of sampled frames")
     ap.add_argument("--context", choices=["hip", "emu"], default="hip", help="emu = CPU emulator + gloo (tests of this file's rank logic only)")
     ap.add_argument("--chunk-bytes", type=int, default=synth.CHUNK_BYTES, help="tests only; the metric is defined on 8 MiB chunks")
+    ap.add_argument("--depth", type=int, default=0, help="steps in flight (0 = 2 when one step's frames leave room for a second set of frame slots, else 1): "
+                    "step k + 1's compressor runs while step k's digest chains finish, the way the gateway operator's lanes overlap their batches")
     ap.add_argument("--halves", type=int, default=0, help="tests only: resident halves per step (0 = 2 when the stream has more than 8192 chunks)")
     args = ap.parse_args()
 
@@ -262,11 +264,24 @@ def main():
     stride = (bound + 255) & ~255
     halves = args.halves or (2 if (n_target > 8192 and not args.cdc) else 1)          # frame slots are reused by the second half
     n_chunks = n_target
+    depth = args.depth or (1 if (emu or args.cdc or halves > 1) else 2)
     if not emu:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
-        scratch = 2 * args.max_batch * 128 * 66048          # the library double-buffers its block scratch
-        while n_chunks > 64 and n_chunks * cb + (n_chunks // halves) * stride + scratch + (6 << 30) > free_b:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        frames_min = int(os.environ.get("SKYHIP_FRAMES_MIN", 2 * cus))      # (the library's rule: skyhip.hip)
+
+        def need(n, d):
+            in_place = frames_min > 0 and n >= frames_min
+            scratch = 0 if in_place else int(2.5 * args.max_batch * 128 * 66048)      # block scratch, double-buffered, only on the block-queue path
+            return n * cb + d * (n // halves) * stride + d * scratch + (6 << 30)
+
+        if depth > 1 and need(n_chunks, depth) > free_b:
+            depth = 1
+        while n_chunks > 64 and need(n_chunks, depth) > free_b:
             n_chunks //= 2
+        in_place = frames_min > 0 and n_chunks >= frames_min
+    else:
+        in_place = False
     if world > 1:   # every rank processes the same number of chunks (weak scaling: value = world x chunks x bytes / time)
         nc = torch.tensor([n_chunks], dtype=torch.int64, device=dev)
         dist.all_reduce(nc, op=dist.ReduceOp.MIN)
@@ -290,7 +305,8 @@ def main():
             tile = tile ^ (t & 0xFF)      # keep the unit's internal duplicate structure, make tiles mutually distinct
         d_in[lo:hi] = tile
     del d_unit
-    d_out = torch.empty(n_half * stride, dtype=torch.uint8, device=dev)
+    d_outs = [torch.empty(n_half * stride, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    d_out = d_outs[0]
     if not emu:
         torch.cuda.synchronize(dev)
     gen_s = time.perf_counter() - t0
@@ -302,37 +318,80 @@ def main():
     out_off_all, out_cap_all = np.tile(out_off, halves), np.tile(out_cap, halves)
 
     if emu:
-        ctx = EmuContext()
-        p_in, p_out = d_in.numpy(), d_out.numpy()
+        ctxs = [EmuContext()]
+        p_in, p_outs = d_in.numpy(), [d_out.numpy()]
     else:
-        ctx = hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch)
-        p_in, p_out = d_in.data_ptr(), d_out.data_ptr()
+        ctxs = [hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch) for _ in range(depth)]
+        p_in, p_outs = d_in.data_ptr(), [t.data_ptr() for t in d_outs]
+    ctx = ctxs[0]
     flags = hip_ops.F_LZ4 | hip_ops.F_MD5 | ((hip_ops.F_CDC | hip_ops.F_DEDUP) if args.cdc else 0)
-    last = {}
+    lasts = [{} for _ in range(depth)]
 
-    def step():
+    def step(lane=0):
         if args.cdc:
-            ctx.dedup_reset()      # every step sees the stream for the first time
-        # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the LZ4
-        # sub-batches of both halves; the second half's frames take over the first half's slots (s_fr orders the writes)
-        last["out_len"], last["md5"] = ctx.process_device(p_in, in_off, in_len, p_out, out_off_all, out_cap_all, flags)
+            ctxs[lane].dedup_reset()      # every step sees the stream for the first time
+        # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the compressor;
+        # with two resident halves the second half's frames take over the first half's slots (the chunk queue hands chunks out in index order:
+        # a slot's first frame is complete thousands of chunks before its second one is started)
+        lasts[lane]["out_len"], lasts[lane]["md5"] = ctxs[lane].process_device(p_in, in_off, in_len, p_outs[lane], out_off_all, out_cap_all, flags)
+
+    def run_steps(k_steps):
+        """k_steps steps, `depth` of them in flight: lane j (its own context, streams and frame slots) runs steps j, j + depth, ...  A step's digest
+        chains (one per chunk, ~82 ms when alone, longer beside the compressor) end after its compressor launch does; with a second step in flight the
+        next compressor launch runs meanwhile instead of waiting for them."""
+        if depth == 1:
+            for _ in range(k_steps):
+                step(0)
+            return
+        import threading
+
+        errs = []
+
+        def lane_loop(j):
+            try:
+                for _ in range(j, k_steps, depth):
+                    step(j)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=lane_loop, args=(j,)) for j in range(depth)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def sync():
         if not emu:
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    ctx.reset_timing()
-    _local, elapsed = shard.timed_region(step, args.steps, dist=dist, sync=sync)      # barrier + synchronize on both sides, MAX over ranks
-    tm = ctx.timing()
-    out_len, md5 = last["out_len"], last["md5"]
+    run_steps(args.warmup)
+    if depth > 1 and args.warmup < depth:
+        run_steps(depth - args.warmup)      # every lane's context has run once before the clock starts
+    for c_ in ctxs:
+        c_.reset_timing()
+    _local, elapsed = shard.timed_region(lambda: run_steps(args.steps), 1, dist=dist, sync=sync)      # EXACTLY args.steps steps between barrier + synchronize, MAX over ranks
+    tms = [c_.timing() for c_ in ctxs]
+
+    class _Tm:
+        pass
+
+    tm = _Tm()
+    for f in ("lz4_ms", "layout_ms", "gather_ms", "md5_ms", "cdc_ms", "lz4_launches", "lz4_in_bytes", "lz4_out_bytes", "md5_launches", "md5_in_bytes"):
+        setattr(tm, f, sum(getattr(t, f) for t in tms))
+    last_lane = (args.steps - 1) % depth if args.steps >= depth else 0
+    out_len, md5 = lasts[last_lane]["out_len"], lasts[last_lane]["md5"]
+    d_out = d_outs[last_lane]
+    for j in range(depth):      # every lane hashed and compressed the same stream: same digests, same frame lengths
+        if lasts[j]:
+            assert np.array_equal(lasts[j]["md5"], md5) and np.array_equal(lasts[j]["out_len"], out_len), f"lane {j} disagrees with lane {last_lane}"
     # the second roofline (SURVEY 8d: min(HBM, chain)): MD5 is one serial chain per chunk, so a step can never be shorter than one chain however
     # many lanes idle.  Measured, outside the timed region: the digest kernel alone over the same resident chunks.
     md5_alone_ms = None
     if not emu and rank == 0:
         ctx.reset_timing()
-        ctx.process_device(p_in, in_off, in_len, p_out, out_off_all, out_cap_all, hip_ops.F_MD5)
+        ctx.process_device(p_in, in_off, in_len, p_outs[0], out_off_all, out_cap_all, hip_ops.F_MD5)
         md5_alone_ms = ctx.timing().md5_ms
 
     # ---- verification, outside the timed region: every digest of the last step, a sample of the frames of its last half ----
@@ -395,7 +454,7 @@ def main():
         # chunk; the 16-byte digest and cut offsets are negligible), divided by the HIP-event duration of that kernel on the library's stream.
         lz4_s = tm.lz4_ms / 1e3
         achieved = (tm.lz4_in_bytes + tm.lz4_out_bytes) / lz4_s / 1e9 if lz4_s > 0 else 0.0
-        kname = "sky_lz4s_compress"
+        kname = "sky_lz4s_frames" if in_place else "sky_lz4s_compress"      # large device-resident batches: frames written in place (skyhip.hip)
         res = {
             "metric": "GiB/s through compress+hash stage (input bytes)", "value": round(value, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -403,7 +462,8 @@ def main():
             "config": {"workload": f"{cfg_id}: {world} MI355X, {cb >> 20} MiB chunks, LZ4 frame + MD5 HIP kernels, {sdesc}; "
                                    f"{n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks per step in {halves} resident half(s), {unit_bytes >> 20} MiB unit tiled + rotated",
                        "chunk_bytes": cb, "chunks_per_gpu": n_chunks, "lz4_ratio": round(n_chunks * cb / comp_bytes, 4),
-                       "sharding": "chunk i of the node's queue on rank i % N, no collective on the data path" if world > 1 else "single GPU", "max_batch": args.max_batch},
+                       "sharding": "chunk i of the node's queue on rank i % N, no collective on the data path" if world > 1 else "single GPU", "max_batch": args.max_batch,
+                       "steps_in_flight": depth, "lz4_path": "frames written in place, one launch per step" if in_place else "block queue + frame gather, sub-batches of max_batch"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "avg_launch_ms": round(tm.lz4_ms / max(tm.lz4_launches, 1), 4), "launches": int(tm.lz4_launches),
@@ -418,10 +478,11 @@ def main():
             chain = n_chunks * cb / (md5_alone_ms / 1e3) / 2**30
             res["roofline"]["chain"] = {
                 "kernel": "sky_md5_chunks", "md5_alone_ms": round(md5_alone_ms, 3), "per_chain_MBps": round(cb / (md5_alone_ms / 1e3) / 1e6, 2),
-                "resident_chains": int(n_chunks), "bound_GiBps": round(chain, 1), "hbm_bound_GiBps": round(hbm_in, 1),
-                "min_bound": "chain" if chain < hbm_in else "hbm", "frac_of_min_bound": round(value / world / min(chain, hbm_in), 4),
-                "note": "whole-chunk MD5 is a serial dependency chain per chunk (RFC 1321): with every chunk of the step resident and hashed concurrently the "
-                        "step cannot be shorter than one chain; bound = resident chains x measured per-chain rate (rank 0's GPU)"}
+                "resident_chains": int(n_chunks * depth), "bound_GiBps": round(chain * depth, 1), "hbm_bound_GiBps": round(hbm_in, 1),
+                "min_bound": "chain" if chain * depth < hbm_in else "hbm", "frac_of_min_bound": round(value / world / min(chain * depth, hbm_in), 4),
+                "note": "whole-chunk MD5 is a serial dependency chain per chunk (RFC 1321): a chunk's digest cannot arrive sooner than one chain however many "
+                        "lanes idle, and the stage's throughput cannot exceed resident chains x measured per-chain rate (rank 0's GPU); resident = the chunks of "
+                        "the steps in flight"}
         # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (scripts/pmc.sh); a committed measurement is
         # quoted only for the kernel and stream it was taken on
         tf = ROOT / "profiles" / "traffic.json"
@@ -463,7 +524,8 @@ def main():
         print(json.dumps(res), flush=True)
     if pool is not None:
         pool.close(); pool.join()
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

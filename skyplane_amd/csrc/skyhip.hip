@@ -9,6 +9,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "skyhip.h"
 #include "wave.h"
@@ -46,6 +47,16 @@ extern "C" __global__ void __launch_bounds__(LZ4S_LANES) LZ4S_KERNEL_ATTR sky_lz
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #endif
     sky_lz4s_compress_body(a, smem);
+}
+// the same compressor writing whole frames in place (one workgroup per chunk at a time; lz4s_kernel.inc): large device-resident batches
+extern "C" __global__ void __launch_bounds__(LZ4S_LANES) LZ4S_KERNEL_ATTR sky_lz4s_frames(SkyLz4FArgs a) {
+#if LZ4S_ABS_LDS
+    typedef __attribute__((address_space(3))) uint8_t sky_lds_u8;
+    uint8_t* smem = (uint8_t*)(sky_lds_u8*)(uintptr_t)LZ4S_LDS_ORIGIN;
+#else
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#endif
+    sky_lz4s_frames_body(a, smem);
 }
 #ifndef SKY_MD5_KERNEL_ATTR
 #define SKY_MD5_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: fits in what four compressor waves leave of a SIMD
@@ -183,6 +194,7 @@ struct skyhip_ctx {
                                   // load instruction), and a CU's memory path serves one such wave at full chain speed -- 2048 chunks take 98 ms as 64-lane
                                   // workgroups, 187 ms as 256-lane, 374 ms as 512-lane ones (profiles/r2_md5_workgroup.txt).  SKYHIP_MD5_WG overrides.
     bool md5_wg_env = false;      // SKYHIP_MD5_WG given: no automatic choice
+    int frames_min = 0;           // a device-resident call with at least this many chunks uses sky_lz4s_frames (one workgroup per chunk at a time)
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
     DevBuf<sky_u64> d_blk_dst[2];
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
@@ -321,17 +333,16 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_cdc, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
-        const size_t nb = (size_t)max_batch * c->blocks_per_chunk;
-        for (int k = 0; k < 2; k++) {
-            HIPCHK(c, c->d_scratch[k].ensure(nb * SKY_LZ4_SLOT));
-            HIPCHK(c, c->d_csize[k].ensure(nb));
-            HIPCHK(c, c->d_blk_word[k].ensure(nb));
-            HIPCHK(c, c->d_blk_dst[k].ensure(nb));
-        }
+        // (the block scratch of the block-queue path -- 8.06 MiB per chunk of max_batch, twice -- is allocated by the first call that takes that path:
+        // a context that only ever sees large device-resident batches writes its frames in place and never needs it)
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_link, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4D_LINK_LDS));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
+        // frames in place need a chunk per CU (and then some, for balance) to fill the chip; below that the block queue + gather keeps every CU busy
+        c->frames_min = 2 * c->lz4s_grid;
+        if (const char* e = getenv("SKYHIP_FRAMES_MIN")) { const int v = atoi(e); if (v >= 0) c->frames_min = v; }
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_frames, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES));
         HIPCHK(c, c->d_queue.ensure(16));
         { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) { c->md5_wg = v; c->md5_wg_env = true; } }
 #ifdef SKY_WITH_CDC
@@ -352,9 +363,22 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
     return SKYHIP_OK;
 }
 
+// ---- one whole-chip compressor launch at a time per device --------------------------------------------------------------------------------
+// sky_lz4s_frames takes every CU's LDS: two of them (two contexts of one process, e.g. the lanes of an operator or the steps bench.py keeps in
+// flight) cannot share the chip, the second one's workgroups only trickle in as the first one's exit.  So a context makes its stream wait for the
+// previous such launch of ANY context on the device before it records its own start event: the launches run back to back, and the event pair around
+// each one times the kernel, not the queueing.  (Streams of different contexts are ordered through an event; nothing blocks on the host.)
+static std::mutex g_frames_mu;
+static hipEvent_t g_frames_last[64] = {};        // per device: completion event of the most recent sky_lz4s_frames launch, owned by its context
+static skyhip_ctx* g_frames_owner[64] = {};
+
 void skyhip_destroy(skyhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
+    {
+        std::lock_guard<std::mutex> lk(g_frames_mu);
+        if (c->dev >= 0 && c->dev < 64 && g_frames_owner[c->dev] == c) { g_frames_owner[c->dev] = nullptr; g_frames_last[c->dev] = nullptr; }
+    }
     if (c->s_lz4) (void)hipStreamSynchronize(c->s_lz4);
     if (c->s_fr) (void)hipStreamSynchronize(c->s_fr);
     if (c->s_md5) (void)hipStreamSynchronize(c->s_md5);
@@ -484,7 +508,41 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
     }
     // ---- LZ4: sub-batches of max_batch chunks; the compressor (s_lz4) writes block scratch k & 1 while the frames of sub-batch k-1 are laid out
     //      and gathered out of the other buffer on s_fr ----
-    if (flags & SKYHIP_F_LZ4) {
+    const bool frames_in_place = (flags & SKYHIP_F_LZ4) && !pipe && c->frames_min > 0 && N >= (size_t)c->frames_min;
+    if (frames_in_place) {
+        // ---- LZ4, large device-resident batch: ONE launch, a workgroup per chunk at a time, every frame written in place (no scratch, no gather) ----
+        SkyLz4FArgs fa;
+        fa.in = (const uint8_t*)d_in; fa.in_off = c->d_in_off.p; fa.in_len = c->d_in_len.p; fa.n_chunks = (uint32_t)N;
+        fa.out = (uint8_t*)d_out; fa.out_off = c->d_out_off.p; fa.frame_len = c->d_frame_len.p; fa.prof = nullptr; fa.queue = c->d_queue.p;
+#if SKY_PROF
+        if (!c->d_prof) { HIPCHK(c, hipMalloc((void**)&c->d_prof, 64 * 16 * 8)); HIPCHK(c, hipMemset(c->d_prof, 0, 64 * 16 * 8)); }
+        fa.prof = c->d_prof;
+#endif
+        HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4, c->s_lz4));     // chunk queue head
+        EvPair ep;
+        {
+            std::lock_guard<std::mutex> lk(g_frames_mu);          // (see g_frames_last: launches of all contexts on this device run back to back)
+            const int dv = c->dev >= 0 && c->dev < 64 ? c->dev : 0;
+            if (g_frames_last[dv] && g_frames_owner[dv] != c) HIPCHK(c, hipStreamWaitEvent(c->s_lz4, g_frames_last[dv], 0));
+            if ((rc = ev_begin(c, c->s_lz4, K_LZ4, &ep))) return rc;
+            hipLaunchKernelGGL(sky_lz4s_frames, dim3(N < (size_t)c->lz4s_grid ? (unsigned)N : (unsigned)c->lz4s_grid), dim3(LZ4S_LANES), LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES, c->s_lz4, fa);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = ev_end(c, c->s_lz4, ep))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev_lz4_done[0], c->s_lz4));
+            g_frames_last[dv] = c->ev_lz4_done[0]; g_frames_owner[dv] = c;
+        }
+        c->tm.lz4_launches++; c->tm.lz4_in_bytes += bytes_total;
+        HIPCHK(c, hipMemcpyAsync(c->h_frame_len.p, c->d_frame_len.p, N * 8, hipMemcpyDeviceToHost, c->s_lz4));
+    } else if (flags & SKYHIP_F_LZ4) {
+        {
+            const size_t nbmax = (size_t)c->max_batch * c->blocks_per_chunk;
+            for (int k = 0; k < 2; k++) {
+                HIPCHK(c, c->d_scratch[k].ensure(nbmax * SKY_LZ4_SLOT));
+                HIPCHK(c, c->d_csize[k].ensure(nbmax));
+                HIPCHK(c, c->d_blk_word[k].ensure(nbmax));
+                HIPCHK(c, c->d_blk_dst[k].ensure(nbmax));
+            }
+        }
         size_t sub = 0;
         for (size_t c0 = 0; c0 < N; c0 += (size_t)c->max_batch, sub++) {
             const int bf = (int)(sub & 1);

@@ -56,6 +56,7 @@ SKY_DEV uint32_t sky_scan_incl_add_shfl(uint32_t v) { return (uint32_t)emu_colle
 SKY_DEV void sky_sched_fence() {}
 template <int P> SKY_DEV void sky_setprio() {}
 SKY_DEV void sky_syncthreads() { emu_collective(EMU_BARRIER, 0, 0); }
+SKY_DEV void sky_syncthreads_lds() { emu_collective(EMU_BARRIER, 0, 0); }
 // lanes of the emulator run one after the other between collectives; on hardware they run in lock-step, and the
 // kernels put a wave fence wherever a lane reads what another lane of the same wave just wrote: make it a rendezvous
 SKY_DEV void sky_wave_fence() { emu_collective(EMU_WAVESYNC, 0, 0); }

@@ -17,6 +17,7 @@
 #endif
 
 static void k_lz4s(void* a, uint8_t* smem) { sky_lz4s_compress_body(*(SkyLz4Args*)a, smem); }
+static void k_lz4s_frames(void* a, uint8_t* smem) { sky_lz4s_frames_body(*(SkyLz4FArgs*)a, smem); }
 static void k_md5(void* a, uint8_t*) { sky_md5_body(*(SkyMd5Args*)a); }
 static void k_layout(void* a, uint8_t*) { sky_frame_layout_body(*(SkyFrameArgs*)a); }
 static void k_gather(void* a, uint8_t*) { sky_frame_gather_body(*(SkyFrameArgs*)a); }
@@ -41,7 +42,15 @@ int emu_process(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_le
         SkyMd5Args ma; ma.in = in; ma.off = off.data(); ma.len = len.data(); ma.n = (uint32_t)n; ma.digest = md5;
         emu_launch((n + 63) / 64, 64, 0, k_md5, &ma);
     }
-    if (flags & 1u) {
+    if ((flags & 5u) == 5u) {      // frames written in place: a workgroup per chunk at a time (what libskyhip does for large device-resident batches)
+        std::vector<sky_u64> flen(n);
+        SkyLz4FArgs fa; fa.in = in; fa.in_off = off.data(); fa.in_len = len.data(); fa.n_chunks = (uint32_t)n; fa.out = out; fa.out_off = ooff.data();
+        fa.frame_len = flen.data(); fa.prof = nullptr;
+        uint32_t qhead = 0;
+        fa.queue = &qhead;
+        if (n) emu_launch(n < 2 ? n : 2, LZ4S_LANES, LZ4S_LDS_BYTES, k_lz4s_frames, &fa);      // two workgroups: each walks several chunks
+        for (int i = 0; i < n; i++) frame_len[i] = flen[i];
+    } else if (flags & 1u) {
         std::vector<uint8_t> scratch((size_t)(nb ? nb : 1) * SKY_LZ4_SLOT, 0xCD);
         std::vector<uint32_t> csize(nb ? nb : 1), word(nb ? nb : 1);
         std::vector<sky_u64> bdst(nb ? nb : 1), flen(n);

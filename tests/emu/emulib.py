@@ -80,7 +80,7 @@ def _pack_inputs(chunks, guard):
     return in_off, addr, keep
 
 
-def process(chunks, flags=3, blk_skew=0, guard=None):
+def _process_once(chunks, flags=3, blk_skew=0, guard=None):
     """chunks: list of bytes. Returns (frames: list[bytes], md5s: list[bytes], csizes).
     guard: None | "end" | "start" -- see Guarded; input AND output buffers are then exactly as large as the C ABI
     promises (sum of chunk bytes / frame bounds) and fenced by inaccessible pages."""
@@ -113,6 +113,16 @@ def process(chunks, flags=3, blk_skew=0, guard=None):
         if flags & 1:
             assert (out[end:nxt] == 0xEE).all(), f"frame {i} wrote past its length"
     return frames, [md5[i].tobytes() for i in range(n)], cs[:nb]
+
+
+def process(chunks, flags=3, blk_skew=0, guard=None):
+    """Both launch sequences of libskyhip under the emulator: block queue + scratch + frame layout / gather (small batches) and frames written in place
+    by a workgroup per chunk (large device-resident batches).  Their frames must be the same bytes; the first path's results are returned."""
+    res = _process_once(chunks, flags, blk_skew, guard)
+    if flags & 1:
+        again = _process_once(chunks, (flags & ~2) | 4, 0, guard)
+        assert again[0] == res[0], "frames written in place differ from the frames the gather pass puts together"
+    return res
 
 
 class EmuCdc:
