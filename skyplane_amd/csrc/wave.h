@@ -185,6 +185,14 @@ SKY_DEV void sky_st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 struct sky_u128 { uint32_t x, y, z, w; };
 SKY_DEV sky_u128 sky_ld128u(const uint8_t* p) { sky_u128 v; __builtin_memcpy(&v, p, 16); return v; }
+// the same as ONE 16-byte access whatever the optimizer thinks of the four fields' uses (a memcpy into a struct may be split into two 8-byte
+// loads, and on LDS two misaligned loads cost twice what one does: a lane per cycle each)
+#ifdef SKY_EMU
+SKY_DEV sky_u128 sky_ld128u1(const uint8_t* p) { return sky_ld128u(p); }
+#else
+typedef uint32_t sky_v4u_b1 __attribute__((ext_vector_type(4), aligned(1)));
+SKY_DEV sky_u128 sky_ld128u1(const uint8_t* p) { const sky_v4u_b1 t = *(const sky_v4u_b1*)p; sky_u128 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
+#endif
 SKY_DEV void sky_st128u(uint8_t* p, const sky_u128& v) { __builtin_memcpy(p, &v, 16); }
 SKY_DEV void sky_st64u(uint8_t* p, sky_u64 v) { __builtin_memcpy(p, &v, 8); }
 // naturally aligned forms (one ds_read_b128 / ds_write_b128 / b64 / b32 on LDS)
