@@ -155,6 +155,58 @@ def test_device_resident_batch_matches_oracle(ctx):
     assert t.lz4_ms > 0 and t.md5_ms > 0 and t.lz4_in_bytes >= n * cb
 
 
+def test_frames_written_in_place_equal_the_gathered_frames(monkeypatch):
+    """Round 4: device-resident batches of >= 2 chunks per CU take sky_lz4s_frames (a workgroup per chunk at a time writes header, size words, blocks and
+    EndMark straight into the frame), smaller ones the block queue + sky_frame_layout / sky_frame_gather.  Forced through BOTH here (SKYHIP_FRAMES_MIN is read
+    when a context is created) over ragged, empty, tiny, incompressible and run-length chunks at misaligned input and frame offsets: the frames must be the
+    same bytes, equal the sequential model block by block, decode with liblz4, and nothing may be written outside a frame's own length."""
+    from skyplane_amd import hip_ops
+
+    rng = synth.rng_for(0, 4242)
+    sizes = [0, 1, 12, 13, 64, 4095, 65535, 65536, 65537, 131072 + 5, 200_000, (1 << 20) + 77, 3 * 65536, 65536 * 2 - 1, 70_001, 1 << 20]
+    chunks = [synth.gen_class(synth.CLASSES[i % len(synth.CLASSES)], s, rng).tobytes() if s else b"" for i, s in enumerate(sizes)]
+    chunks += [bytes(300_000), b"ab" * 40_000 + bytes(5) + b"ab" * 30_000, synth.gen_random(rng, 65536 * 2 + 9).tobytes(), b"\x01" * 70_000 + b"\x02" * 70_000]
+    n = len(chunks)
+    in_off, pos = np.zeros(n, np.uint64), 3
+    for i, c in enumerate(chunks):
+        in_off[i] = pos
+        pos += len(c) + 7                                   # 7: odd gaps, every alignment of a chunk's first byte
+    host_in = np.full(pos + 64, 0x5A, np.uint8)
+    for i, c in enumerate(chunks):
+        host_in[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+    in_len = np.array([len(c) for c in chunks], np.uint64)
+    out_off, pos = np.zeros(n, np.uint64), 5
+    for i, c in enumerate(chunks):
+        out_off[i] = pos
+        pos += hip_ops.frame_bound(len(c)) + 11
+    out_cap = np.array([hip_ops.frame_bound(len(c)) for c in chunks], np.uint64)
+    d_in = torch.from_numpy(host_in).cuda()
+    got = {}
+    for mode, fmin in (("in place", "1"), ("gathered", "0")):
+        monkeypatch.setenv("SKYHIP_FRAMES_MIN", fmin)
+        c = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=2 << 20, max_batch=8)
+        try:
+            d_out = torch.full((pos + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            out_len, md5 = c.process_device(d_in.data_ptr(), in_off, in_len, d_out.data_ptr(), out_off, out_cap)
+            t = c.timing()
+            assert t.gather_ms == 0 if mode == "in place" else t.gather_ms > 0, mode       # the path that was asked for is the path that ran
+            got[mode] = (out_len.copy(), md5.copy(), d_out.cpu().numpy())
+        finally:
+            c.close()
+    (la, ma, fa), (lb, mb, fb) = got["in place"], got["gathered"]
+    assert (la == lb).all() and (ma == mb).all()
+    for i, c in enumerate(chunks):
+        o, ln = int(out_off[i]), int(la[i])
+        frame = fa[o:o + ln].tobytes()
+        assert frame == fb[o:o + ln].tobytes(), f"chunk {i} ({len(c)} bytes): frames differ between the two paths"
+        assert ma[i].tobytes() == hashlib.md5(c).digest()
+        assert ref.lz4f_decompress(frame, len(c)) == c
+        lz4smodel.check_frame(c, frame)
+        nxt = int(out_off[i + 1]) if i + 1 < n else fa.size
+        assert (fa[o + ln:nxt] == 0xEE).all() and (fa[:int(out_off[0])] == 0xEE).all(), f"chunk {i}: bytes written outside the frame"
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Gear CDC + segment fingerprints + dedup table (new capability; spec = oracle/skyoracle.c, parity unpinned)
 # ---------------------------------------------------------------------------------------------------------
