@@ -29,6 +29,9 @@
                                // takes 1.8 % off the kernel for 0.03 % / 0.09 % of ratio on the Silesia-like stream, but sparse data (long runs) then exceeds the reference's
                                // frames by 10.1 % / 14.6 % against 8.4 % -- over the 10 % every class is held to (tests/test_gpu_parity.py): stays at 256
 #endif
+#ifndef LZ4S_PER1
+#define LZ4S_PER1 0            // 1 = distance-1 candidates (runs found at their second byte)
+#endif
 #ifndef LZ4S_BACK
 #define LZ4S_BACK 8u           // a match start may move back over at most this many pending literals
 #endif

@@ -47,7 +47,8 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
     if (n >= 13u) {
         const uint32_t mflimit = n - 12u, matchlimit = n - 5u;
         // pre-pass: earliest position per (bucket, region) among equal tags; every LZ4S_INS_STEP-th position from LZ4S_FIRST_INS on is entered
-        for (uint32_t p = LZ4S_FIRST_INS; p <= mflimit; p += LZ4S_INS_STEP) {
+        for (uint32_t p = LZ4S_FIRST_INS; p <= mflimit; p++) {
+            if (((p & (LZ4S_SLICE - 1u)) % LZ4S_INS_STEP) != 0u) continue;      // positions 0, STEP, 2 STEP, ... of every 64-byte slice
             const uint32_t x = LZ4S_HASH(rd32(s + p), s[p + 4]);
             uint32_t* e = &T[LZ4S_BUCKET(x) * LZ4S_Q + (p >> LZ4S_RLOG)];
             const uint32_t v = LZ4S_ENTRY(LZ4S_TAG(x), p & ((1u << LZ4S_RLOG) - 1u));
@@ -70,6 +71,10 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                 // short-period candidate (runs, "abab", 32-bit patterns): the 4 bytes before p repeat at p.  Overlapping
                 // copies run as long as the period holds, which no table entry (the EARLIEST occurrence) can offer.
                 if (p >= 4u && rd32(s + p - 4u) == rd32(s + p)) { best = common(s + p, s + p - 4u, cap8); bc = p - 4u; cand = 1; }
+#if LZ4S_PER1
+                // distance 1 (a run of one byte value begins at p - 1): found at the run's second byte, where the distance-4 test needs its fifth
+                if (p >= 1u && rd32(s + p - 1u) == rd32(s + p)) { const uint32_t l = common(s + p, s + p - 1u, cap8); if (l >= best) { best = l; bc = p - 1u; } cand = 1; }
+#endif
                 // best = the longest of the candidates, ties to the nearest (largest position)
                 for (int k = (int)q; k >= 0; k--) {                   // nearest region first; a farther one must be strictly longer
                     const uint32_t d = e[k] - tb;
@@ -100,7 +105,7 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                 if (lz4s_dbg_trace && lz4s_dbg_ntrace < lz4s_dbg_trace_cap) lz4s_dbg_trace[lz4s_dbg_ntrace++] = j | this_visit << 10 | validmask << 14 | (extsteps > 16383u ? 16383u : extsteps) << 18;
                 // move the start back over pending literals: at most LZ4S_BACK bytes, 4 when the match is the distance-4 one (the kernel has the
                 // 8 bytes before every table candidate in registers, but only 4 of the 8 before position p - 4)
-                const uint32_t backmax = bc + 4u == p ? 4u : LZ4S_BACK;
+                const uint32_t backmax = (bc + 4u == p || (LZ4S_PER1 && bc + 1u == p)) ? 4u : LZ4S_BACK;
                 uint32_t nb = 0;
                 while (nb < backmax && p - nb > lanchor && bc - nb > 0u && s[p - nb - 1u] == s[bc - nb - 1u]) nb++;
                 const uint32_t mp = p - nb, c0 = bc - nb;
