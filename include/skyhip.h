@@ -105,7 +105,12 @@ int  skyhip_host_unregister(skyhip_ctx* ctx, void* p);
 /* Device-resident batch (kernel-only path: inputs already in HBM, PCIe excluded).
  * d_in / d_out are DEVICE pointers on ctx's device; in_off/in_len/out_off/out_cap are HOST arrays of
  * byte offsets into d_in / d_out.  out_len (host, may be NULL) and md5 (host, may be NULL) are filled
- * after the batch completes.  Frames are written at d_out + out_off[i]. */
+ * after the batch completes.  Frames are written at d_out + out_off[i].
+ * A batch of at least two chunks per CU of the device (environment SKYHIP_FRAMES_MIN at skyhip_create: another threshold, 0 = never) is compressed by ONE
+ * launch in which a workgroup takes a whole chunk at a time and writes its frame in place -- header, block size words, blocks, EndMark --; smaller
+ * batches go block by block through scratch slots and a gather pass.  Both produce the same bytes.  Frame regions [out_off[i], out_off[i] + out_cap[i])
+ * must not overlap unless the caller accepts that the chunk started later wins (chunks are started in index order).  Two contexts of one process may
+ * call this concurrently (one host thread each): their whole-chip compressor launches are queued back to back on the device, their digest kernels overlap. */
 int  skyhip_process_device(skyhip_ctx* ctx, int n,
                            const void* d_in, const uint64_t* in_off, const uint64_t* in_len,
                            void* d_out, const uint64_t* out_off, const uint64_t* out_cap,
