@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--verify", choices=["full", "sample", "none"], default="full", help="post-run check of digests (all / 64 chunks) and of sampled frames")
     ap.add_argument("--context", choices=["hip", "emu"], default="hip", help="emu = CPU emulator + gloo (tests of this file's rank logic only)")
     ap.add_argument("--chunk-bytes", type=int, default=synth.CHUNK_BYTES, help="tests only; the metric is defined on 8 MiB chunks")
-    ap.add_argument("--depth", type=int, default=0, help="steps in flight (0 = 2 when one step's frames leave room for a second set of frame slots, else 1): "
+    ap.add_argument("--depth", type=int, default=0, help="steps in flight (0 = 2 when a second set of frame slots fits beside the stream, else 1): "
                     "step k + 1's compressor runs while step k's digest chains finish, the way the gateway operator's lanes overlap their batches")
     ap.add_argument("--halves", type=int, default=0, help="tests only: resident halves per step (0 = 2 when the stream has more than 8192 chunks)")
     args = ap.parse_args()
@@ -264,7 +264,7 @@ def main():
     stride = (bound + 255) & ~255
     halves = args.halves or (2 if (n_target > 8192 and not args.cdc) else 1)          # frame slots are reused by the second half
     n_chunks = n_target
-    depth = args.depth or (1 if (emu or args.cdc or halves > 1) else 2)
+    depth = args.depth or (1 if (emu or halves > 1) else 2)
     if not emu:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -494,7 +494,7 @@ def main():
                 res["roofline"]["traffic_source"] = t["source"]
         if args.cdc:
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
-            prefix, cuts, fps, first, base = ctx.cdc_results(n_chunks, in_len)
+            prefix, cuts, fps, first, base = ctxs[last_lane].cdc_results(n_chunks, in_len)      # (the context that ran the last step)
             seg_end = cuts.astype(np.int64)
             seg_start = np.concatenate([[0], seg_end[:-1]])
             seg_start[prefix[:-1][prefix[:-1] < prefix[1:]].astype(np.int64)] = 0      # first segment of every chunk starts at 0
