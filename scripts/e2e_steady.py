@@ -161,11 +161,26 @@ def main():
         dd_stream = synth.dedup_stream((a.connections + a.chunks) * size, dup_fraction=0.5, config_id=3) if a.dedup_wire else None
         digests = {}
 
+        # Without --dedup-wire the stream is four chunk contents in turn: they are written and hashed ONCE and every chunk file is a hard link (the operators only
+        # read the source's files, and the daemon API's unlink of `<id>.chunk` drops a name, not the data) -- set-up used to write and hash every one of the
+        # thousand-odd files (60-80 s around a 2 s measurement, NOTES.md), which is what kept the runs too short for their pipeline fill and drain not to show.
+        proto = {}
+
         def make(i):
             cid = uuid.uuid4().hex
-            data = base[i % 4].tobytes() if dd_stream is None else dd_stream[i * size:(i + 1) * size].tobytes()
-            src.get_chunk_file_path(cid).write_bytes(data)
-            digests[cid] = hashlib.md5(data).digest()
+            if dd_stream is None:
+                k = i % 4
+                if k not in proto:
+                    data = base[k].tobytes()
+                    pp = Path(tmp) / f"proto{k}.bin"
+                    pp.write_bytes(data)
+                    proto[k] = (pp, hashlib.md5(data).digest())
+                os.link(proto[k][0], src.get_chunk_file_path(cid))
+                digests[cid] = proto[k][1]
+            else:
+                data = dd_stream[i * size:(i + 1) * size].tobytes()
+                src.get_chunk_file_path(cid).write_bytes(data)
+                digests[cid] = hashlib.md5(data).digest()
             return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
 
         warm = [make(i) for i in range(K)]              # one per connection
@@ -270,9 +285,15 @@ def main():
         rx.join(60)
         assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
         assert n_dec == a.chunks and n_rx == total
-        for cr in (warm + main_reqs if a.context != "null" else []):
-            got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
-            assert hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+        if a.context != "null":           # every chunk that arrived, hashed on all the cores the container may use
+            from concurrent.futures import ThreadPoolExecutor
+
+            def check(cr):
+                got = (dst / f"{cr.chunk.chunk_id}.chunk").read_bytes()
+                return hashlib.md5(got).digest() == digests[cr.chunk.chunk_id] == hip_sender.chunk_digest(src, cr.chunk.chunk_id)
+
+            with ThreadPoolExecutor(max(2, min(16, os.cpu_count() or 2))) as ex:      # (hashlib releases the GIL)
+                assert all(ex.map(check, warm + main_reqs))
         raw = a.chunks * size
         # the rate between the first and the last quarter of the chunks leaving the destination operator: what a transfer of minutes sees, without this
         # run's pipeline fill (the first device call of each side: ~0.1 s each, one MD5 chain) and drain
