@@ -275,6 +275,9 @@ def main():
         elapsed = time.perf_counter() - t0
         for t in threads:
             t.join(60)
+        if err_ev.is_set():               # an operator failed: say why before anything else times out (r5g: 4096 chunks = 32 GiB of destination files did not fit the box's tmpfs)
+            print("operator error:", err_q.get(timeout=5) if not err_q.empty() else "(no message)", file=sys.stderr, flush=True)
+            os._exit(3)
         n_rx = 0
         for _ in range(K):
             n_rx += len(done_q.get(timeout=120))
