@@ -30,13 +30,15 @@
                                // frames by 10.1 % / 14.6 % against 8.4 % -- over the 10 % every class is held to (tests/test_gpu_parity.py): stays at 256
 #endif
 #ifndef LZ4S_PER1
-#define LZ4S_PER1 0            // 1 = distance-1 candidates (runs found at their second byte)
+#define LZ4S_PER1 0            // 1 = distance-1 candidates (runs found at their second byte, where the distance-4 test needs their fifth).  Built and measured in
+                               // round 4 together with LZ4S_INS_STEP 3 (which needs them to keep the sparse class inside its guard): the third fewer table updates
+                               // save what the extra test costs in probe and parse -- 14.76 against 14.79 ms, for 0.5 % of ratio (profiles/r4_lz4s_variants.txt)
 #endif
 #ifndef LZ4S_BACK
 #define LZ4S_BACK 8u           // a match start may move back over at most this many pending literals
 #endif
 #ifndef LZ4S_INS_STEP
-#define LZ4S_INS_STEP 2u       // only every second position enters the table; every position is still looked up.  With a single entry per (bucket, region)
+#define LZ4S_INS_STEP 2u       // positions 0, STEP, 2 STEP, ... of every 64-byte slice enter the table; every position is still looked up.  With a single entry per (bucket, region)
                                // fewer insertions mean fewer evictions: the ratio on the Silesia-like stream is 0.3 % BETTER than with every position
                                // (step 4: 0.8 % worse), a match that starts on an odd position is found one byte later and moved back over the literal
 #endif
