@@ -12,7 +12,7 @@ from oracle import ref
 
 def model(flags):
     so = f"/tmp/mv/m_{abs(hash(flags))}.so"
-    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", f"-I{ROOT}/skyplane_amd/csrc", "-o", so, f"{ROOT}/tests/model/lz4s_model.c"] + flags.split(), check=True)
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", f"-I{ROOT}/skyplane_amd/csrc", "-o", so, os.environ.get("MODEL_SRC", f"{ROOT}/tests/model/lz4s_model.c")] + flags.split(), check=True)
     lib = C.CDLL(so); lib.lz4s_model_block.restype = C.c_uint32; lib.lz4s_model_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     return lib
 def frame_bytes(lib, data):
