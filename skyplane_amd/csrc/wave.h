@@ -149,6 +149,8 @@ SKY_DEV uint32_t sky_shl1_eq(uint32_t bits, uint32_t a, uint32_t b) {
 // returns v, but the compiler may assume nothing about the result (stops CSE / hoisting across this point)
 SKY_DEV uint32_t sky_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 SKY_DEV void sky_keep(uint32_t v) { asm volatile("" ::"v"(v)); }
+// a register whose content nobody will look at (no instruction: spares the zeroing of values that only some paths define)
+SKY_DEV uint32_t sky_undef32() { uint32_t v; asm volatile("" : "=v"(v)); return v; }
 #define SKY_RESTRICT __restrict__
 // shader clock (s_memtime) for the SKY_PROF phase-timing build only
 SKY_DEV sky_u64 sky_clock() { sky_u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }

@@ -103,9 +103,9 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
                     extsteps = (len - 8u + 15u) / 16u + (p + len < lim && ((len - 8u) & 15u) == 0u ? 1u : 0u);   /* 16-byte steps the kernel takes: the last one finds the mismatch (or the limit) */
                 }
                 if (lz4s_dbg_trace && lz4s_dbg_ntrace < lz4s_dbg_trace_cap) lz4s_dbg_trace[lz4s_dbg_ntrace++] = j | this_visit << 10 | validmask << 14 | (extsteps > 16383u ? 16383u : extsteps) << 18;
-                // move the start back over pending literals: at most LZ4S_BACK bytes, 4 when the match is the distance-4 one (the kernel has the
-                // 8 bytes before every table candidate in registers, but only 4 of the 8 before position p - 4)
-                const uint32_t backmax = (bc + 4u == p || (LZ4S_PER1 && bc + 1u == p)) ? 4u : LZ4S_BACK;
+                // move the start back over pending literals: at most LZ4S_BACK bytes (4 as shipped; with a larger value the distance-4 and distance-1
+                // candidates still get 4: the kernel of rounds 2-3 had only 4 of the 8 bytes before position p - 4 in registers)
+                const uint32_t backmax = LZ4S_BACK < 4u ? LZ4S_BACK : ((bc + 4u == p || (LZ4S_PER1 && bc + 1u == p)) ? 4u : LZ4S_BACK);
                 uint32_t nb = 0;
                 while (nb < backmax && p - nb > lanchor && bc - nb > 0u && s[p - nb - 1u] == s[bc - nb - 1u]) nb++;
                 const uint32_t mp = p - nb, c0 = bc - nb;
