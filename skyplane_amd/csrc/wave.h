@@ -47,6 +47,11 @@ SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin
 SKY_DEV void sky_syncthreads() { __syncthreads(); }
 // a barrier that protects LDS contents only: it does not wait for this wavefront's global stores (s_waitcnt vmcnt(0) is part of __syncthreads)
 SKY_DEV void sky_syncthreads_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS DMA: 16 bytes per lane from each lane's own global address straight into LDS at (wave-uniform base) + 16 * lane -- no registers, counted by vmcnt
+SKY_DEV void sky_glds16(const uint8_t* g, uint8_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_wave_base, 16, 0, 0);
+}
 // compiler-only: nothing is scheduled across this point (keeps unrolled load groups from being merged and spilled)
 SKY_DEV void sky_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // s_setprio: issue priority of this wave among the waves of its SIMD (0 = default ... 3)

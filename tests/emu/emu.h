@@ -91,6 +91,7 @@ SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) {      // v_pe
 SKY_DEV uint32_t sky_shl1_lt(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a < b ? 1u : 0u); }
 SKY_DEV uint32_t sky_shl1_eq(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a == b ? 1u : 0u); }
 SKY_DEV void sky_keep(uint32_t) {}
+SKY_DEV void sky_glds16(const uint8_t* g, uint8_t* lds_wave_base) { memcpy(lds_wave_base + 16 * sky_lane(), g, 16); }
 SKY_DEV uint32_t sky_undef32() { return 0xDEADBEEFu; }
 SKY_DEV uint32_t sky_opaque(uint32_t v) { return v; }
 #define SKY_RESTRICT
