@@ -9,6 +9,9 @@
 #include <string.h>
 
 #include "lz4s_spec.h"
+#ifndef LZ4S_PROBE_PAT
+#define LZ4S_PROBE_PAT 0xFu
+#endif
 #ifndef LZ4S_VISITS_MODEL
 #define LZ4S_VISITS_MODEL 12u
 #endif
@@ -77,6 +80,7 @@ uint32_t lz4s_model_block(const uint8_t* s, uint32_t n, uint8_t* dst, lz4s_stats
 #endif
                 // best = the longest of the candidates, ties to the nearest (largest position)
                 for (int k = (int)q; k >= 0; k--) {                   // nearest region first; a farther one must be strictly longer
+                    if (!((LZ4S_PROBE_PAT >> (p & 3u)) & 1u)) break;  // positions whose residue mod 4 is not in the pattern are not looked up (as shipped: all are)
                     const uint32_t d = e[k] - tb;
                     if (!((uint32_t)k < q ? d < 0x10000u : d < rel)) continue;
                     cand = 1;
