@@ -15,6 +15,9 @@ out = {}
 kinds = ("linked (reference default)", "independent (liblz4)", "independent (this library)")
 if os.environ.get("ONLY_LINKED"):
     kinds = kinds[:1]
+if os.environ.get("ONLY_OURS"):
+    kinds = kinds[2:]
+sizes = tuple(int(x) for x in os.environ.get("SIZES", f"{n},32").split(","))
 for kind in kinds:
     if kind.startswith("independent (this"):
         frames = [r.frame for r in ctx.process_batch([c.tobytes() for c in chunks], flags=hip_ops.F_LZ4)]
@@ -31,7 +34,7 @@ for kind in kinds:
     in_len = np.array([len(frames[i % 16]) for i in range(n)], np.uint64)
     out_off = np.arange(n, dtype=np.uint64) * cb; out_cap = np.full(n, cb, np.uint64)
     torch.cuda.synchronize()
-    for bsz in (n, 32):
+    for bsz in sizes:
         sl = slice(0, bsz)
         ctx.decompress_device(d_in.data_ptr(), in_off[sl], in_len[sl], d_out.data_ptr(), out_off[sl], out_cap[sl])
         ctx.decompress_ms(reset=True)

@@ -133,6 +133,13 @@ SKY_DEV sky_u64 sky_atomic_load_u64(const sky_u64* p) { return __hip_atomic_load
 
 SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
+SKY_DEV int sky_clz64(sky_u64 x) { return __builtin_clzll(x); }
+// bit (i mod 64) of a wave-uniform mask set: one s_bitset1_b64 (no shift, no or, no mask of the index)
+SKY_DEV sky_u64 sky_bitset64(sky_u64 m, uint32_t i) { asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(i)); return m; }
+// set bits of a wave-uniform mask below my lane
+SKY_DEV uint32_t sky_mbcnt64(sky_u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// forward permute: every lane sends v to lane `to`; a lane nobody sends to receives 0, the highest sender wins a conflict (ds_permute_b32; no LDS memory involved)
+SKY_DEV uint32_t sky_push(uint32_t to, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(to << 2), (int)v); }
 // full-rate 24-bit integer multiply(-add): v_mul_u32_u24 / v_mad_u32_u24 use the low 24 bits of a and b and return the low 32 bits of the product
 // (a 32-bit v_mul_lo_u32 issues at a quarter of that rate)
 SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }

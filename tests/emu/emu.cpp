@@ -128,6 +128,11 @@ void emu_launch(int grid, int block, size_t lds_bytes, EmuKernelBody body, void*
                             wl[i].result = wl[s].done ? 0 : wl[s].arg0;
                         }
                         break;
+                    case EMU_PUSH: {     // ds_permute_b32: a lane nobody sends to receives 0, the highest sender wins
+                        sky_u64 got[64] = {0};
+                        for (int i = 0; i < 64; i++) if (!wl[i].done) got[(int)wl[i].arg1 & 63] = wl[i].arg0;
+                        for (int i = 0; i < 64; i++) wl[i].result = got[i];
+                    } break;
                     case EMU_SCAN: {
                         uint32_t acc = 0;
                         for (int i = 0; i < 64; i++) { if (!wl[i].done) acc += (uint32_t)wl[i].arg0; wl[i].result = acc; }

@@ -13,7 +13,7 @@
 #define SKY_WAVE 64
 typedef unsigned long long sky_u64;
 
-enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT, EMU_WAVESYNC, EMU_SCANMAX, EMU_YIELD };
+enum EmuOp { EMU_NONE = 0, EMU_BALLOT, EMU_READLANE, EMU_SHFL, EMU_SCAN, EMU_BARRIER, EMU_EXIT, EMU_WAVESYNC, EMU_SCANMAX, EMU_YIELD, EMU_PUSH };
 
 struct EmuLaneState {
     void* sp;            // saved stack pointer of the parked coroutine
@@ -48,6 +48,10 @@ SKY_DEV uint32_t sky_readlane(uint32_t v, int lane) { return (uint32_t)emu_colle
 SKY_DEV uint32_t sky_readfirstlane(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, v, (sky_u64)-1); }
 SKY_DEV uint32_t sky_writelane(uint32_t old, uint32_t val, int lane) { return sky_lane() == lane ? val : old; }
 SKY_DEV uint32_t sky_shfl(uint32_t v, int src) { return (uint32_t)emu_collective(EMU_SHFL, v, (sky_u64)(src & 63)); }
+SKY_DEV uint32_t sky_push(uint32_t to, uint32_t v) { return (uint32_t)emu_collective(EMU_PUSH, v, (sky_u64)(to & 63u)); }
+SKY_DEV sky_u64 sky_bitset64(sky_u64 m, uint32_t i) { return m | (1ull << (i & 63u)); }
+SKY_DEV uint32_t sky_mbcnt64(sky_u64 m) { return (uint32_t)__builtin_popcountll(m & ((1ull << sky_lane()) - 1ull)); }
+SKY_DEV int sky_clz64(sky_u64 x) { return __builtin_clzll(x); }
 SKY_DEV uint32_t sky_scan_incl_add(uint32_t v) { return (uint32_t)emu_collective(EMU_SCAN, v, 0); }
 SKY_DEV uint32_t sky_scan_incl_max(uint32_t v) { return (uint32_t)emu_collective(EMU_SCANMAX, v, 0); }
 SKY_DEV uint32_t sky_wave_max_u32(uint32_t v) { return (uint32_t)emu_collective(EMU_READLANE, emu_collective(EMU_SCANMAX, v, 0), 63); }
