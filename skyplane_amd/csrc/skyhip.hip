@@ -65,7 +65,13 @@ extern "C" __global__ void __launch_bounds__(256) SKY_MD5_KERNEL_ATTR sky_md5_ch
 extern "C" __global__ void __launch_bounds__(256) sky_frame_layout(SkyFrameArgs a) { sky_frame_layout_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_frame_gather(SkyFrameArgs a) { sky_frame_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(64) sky_lz4f_scan(SkyLz4dArgs a) { sky_lz4f_scan_body(a); }
-extern "C" __global__ void __launch_bounds__(256) sky_lz4_decode(SkyLz4dRun r) { sky_lz4_decode_body(r); }
+#ifndef SKY_D_WAVES
+#define SKY_D_WAVES 8      // wavefronts per SIMD the decoder is compiled for: the kernel waits on memory (72 % of its wave-cycles), 64 registers with 14 spilled beat 79 by 16 %
+#endif
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SKY_D_WAVES, 8))) sky_lz4_decode(SkyLz4dRun r) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * SKY_D_STAGE_LDS];      // a batch and a window per wavefront
+    sky_lz4_decode_body(r, smem);
+}
 extern "C" __global__ void __launch_bounds__(256) sky_lz4_parse(SkyLz4dLink r) { sky_lz4_parse_body(r); }
 extern "C" __global__ void __launch_bounds__(SKY_LZ4D_LINK_LANES) sky_lz4_link(SkyLz4dLink r) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

@@ -84,7 +84,7 @@ uint32_t emu_lz4s_block(const uint8_t* src, uint32_t n, uint8_t* dst) {
 uint32_t emu_slot_bytes(void) { return SKY_LZ4_SLOT; }
 
 static void k_dscan(void* a, uint8_t*) { sky_lz4f_scan_body(*(SkyLz4dArgs*)a); }
-static void k_ddec(void* a, uint8_t*) { sky_lz4_decode_body(*(SkyLz4dRun*)a); }
+static void k_ddec(void* a, uint8_t* smem) { sky_lz4_decode_body(*(SkyLz4dRun*)a, smem); }
 static void k_dseq(void* a, uint8_t* smem) { sky_lz4_decode_seq_body(*(SkyLz4dRun*)a, smem); }
 static void k_dparse(void* a, uint8_t*) { sky_lz4_parse_body(*(SkyLz4dLink*)a); }
 static void k_dlink(void* a, uint8_t* smem) { sky_lz4_link_body(*(SkyLz4dLink*)a, smem); }
@@ -128,7 +128,7 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
     }
     if (!items.empty()) {
         SkyLz4dRun r; r.a = a; r.item_slot = items.data(); r.n_items = (uint32_t)items.size();
-        emu_launch(((int)items.size() + 3) / 4, 256, 0, k_ddec, &r);
+        emu_launch(((int)items.size() + 3) / 4, 256, 4 * SKY_D_STAGE_LDS, k_ddec, &r);
     }
     if (!seq.empty()) {
         SkyLz4dRun r; r.a = a; r.item_slot = seq.data(); r.n_items = (uint32_t)seq.size();
