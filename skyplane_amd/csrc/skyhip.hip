@@ -72,7 +72,10 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * SKY_D_STAGE_LDS];      // a batch and a window per wavefront
     sky_lz4_decode_body(r, smem);
 }
-extern "C" __global__ void __launch_bounds__(256) sky_lz4_parse(SkyLz4dLink r) { sky_lz4_parse_body(r); }
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SKY_D_WAVES, 8))) sky_lz4_parse(SkyLz4dLink r) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * SKY_D_STAGE_LDS];
+    sky_lz4_parse_body(r, smem);
+}
 extern "C" __global__ void __launch_bounds__(SKY_LZ4D_LINK_LANES) sky_lz4_link(SkyLz4dLink r) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_link_body(r, smem);

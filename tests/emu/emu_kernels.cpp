@@ -86,7 +86,7 @@ uint32_t emu_slot_bytes(void) { return SKY_LZ4_SLOT; }
 static void k_dscan(void* a, uint8_t*) { sky_lz4f_scan_body(*(SkyLz4dArgs*)a); }
 static void k_ddec(void* a, uint8_t* smem) { sky_lz4_decode_body(*(SkyLz4dRun*)a, smem); }
 static void k_dseq(void* a, uint8_t* smem) { sky_lz4_decode_seq_body(*(SkyLz4dRun*)a, smem); }
-static void k_dparse(void* a, uint8_t*) { sky_lz4_parse_body(*(SkyLz4dLink*)a); }
+static void k_dparse(void* a, uint8_t* smem) { sky_lz4_parse_body(*(SkyLz4dLink*)a, smem); }
 static void k_dlink(void* a, uint8_t* smem) { sky_lz4_link_body(*(SkyLz4dLink*)a, smem); }
 
 // mirrors sky_lz4d_run: scan, build work items, decode.  status[i] = decoder code, out_len[i] = decoded bytes.
@@ -123,7 +123,7 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
         std::vector<uint32_t> ndesc(litems.size());
         SkyLz4dLink r; r.a = a; r.item_slot = litems.data(); r.n_items = (uint32_t)litems.size(); r.desc = desc.data(); r.ndesc = ndesc.data();
         r.frames = lframes.data(); r.first_item = lfirst.data(); r.n_frames = (uint32_t)lframes.size();
-        emu_launch(((int)litems.size() + 3) / 4, 256, 0, k_dparse, &r);
+        emu_launch(((int)litems.size() + 3) / 4, 256, 4 * SKY_D_STAGE_LDS, k_dparse, &r);
         emu_launch((int)lframes.size(), (int)SKY_LZ4D_LINK_LANES, SKY_LZ4D_LINK_LDS, k_dlink, &r);
     }
     if (!items.empty()) {
