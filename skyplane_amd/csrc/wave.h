@@ -146,6 +146,8 @@ SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 // v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {hi, lo} (0-3 = lo's bytes, 4-7 = hi's, 0x0c = 0x00)
 SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// ({hi, lo} >> 8 * (sh & 3)) & 0xFFFFFFFF: v_alignbyte_b32
+SKY_DEV uint32_t sky_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 // bits = 2 * bits + (a < b)  /  + (a == b): a compare into VCC and v_addc_co_u32 bits, bits, bits, vcc -- two VALU instructions per position and no
 // scalar ones, where a compare + select + or costs three and building the union of two conditions an s_or_b64 on top (the scalar unit is the
 // compressor's second-busiest, profiles/r3_pmc_lz4s.txt).  Collecting a lane's bit mask this way fills it from the top: callers walk positions downwards.
