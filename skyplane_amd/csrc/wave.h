@@ -47,11 +47,6 @@ SKY_DEV uint32_t sky_shfl(uint32_t v, int src_lane) { return (uint32_t)__builtin
 SKY_DEV void sky_syncthreads() { __syncthreads(); }
 // a barrier that protects LDS contents only: it does not wait for this wavefront's global stores (s_waitcnt vmcnt(0) is part of __syncthreads)
 SKY_DEV void sky_syncthreads_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// LDS DMA: 16 bytes per lane from each lane's own global address straight into LDS at (wave-uniform base) + 16 * lane -- no registers, counted by vmcnt
-SKY_DEV void sky_glds16(const uint8_t* g, uint8_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
-                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_wave_base, 16, 0, 0);
-}
 // compiler-only: nothing is scheduled across this point (keeps unrolled load groups from being merged and spilled)
 SKY_DEV void sky_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // s_setprio: issue priority of this wave among the waves of its SIMD (0 = default ... 3)
@@ -146,8 +141,6 @@ SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 // v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {hi, lo} (0-3 = lo's bytes, 4-7 = hi's, 0x0c = 0x00)
 SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-// ({hi, lo} >> 8 * (sh & 3)) & 0xFFFFFFFF: v_alignbyte_b32
-SKY_DEV uint32_t sky_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 // bits = 2 * bits + (a < b)  /  + (a == b): a compare into VCC and v_addc_co_u32 bits, bits, bits, vcc -- two VALU instructions per position and no
 // scalar ones, where a compare + select + or costs three and building the union of two conditions an s_or_b64 on top (the scalar unit is the
 // compressor's second-busiest, profiles/r3_pmc_lz4s.txt).  Collecting a lane's bit mask this way fills it from the top: callers walk positions downwards.
@@ -219,16 +212,6 @@ SKY_DEV void sky_st128a(void* p, const sky_u128& v) { __builtin_memcpy(p, &v, 16
 typedef uint32_t sky_v4u __attribute__((ext_vector_type(4)));     // a 16-byte aligned type: one b128 / dwordx4 access
 SKY_DEV sky_u128 sky_ld128a(const void* p) { const sky_v4u t = *(const sky_v4u*)p; sky_u128 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
 SKY_DEV void sky_st128a(void* p, const sky_u128& v) { sky_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(sky_v4u*)p = t; }
-#endif
-// streaming loads of data that is read exactly once: non-temporal, so that they do not push another kernel's lines out of the CU's 32 KiB L1
-#ifdef SKY_EMU
-SKY_DEV sky_u128 sky_ld128_stream(const uint8_t* p) { return sky_ld128u(p); }
-SKY_DEV uint32_t sky_ld32_stream(const uint8_t* p) { return sky_ld32u(p); }
-#else
-typedef uint32_t sky_v4u_u __attribute__((ext_vector_type(4), aligned(1)));
-typedef uint32_t sky_u32_u __attribute__((aligned(1)));
-SKY_DEV sky_u128 sky_ld128_stream(const uint8_t* p) { const sky_v4u t = __builtin_nontemporal_load((const sky_v4u_u*)p); sky_u128 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
-SKY_DEV uint32_t sky_ld32_stream(const uint8_t* p) { return __builtin_nontemporal_load((const sky_u32_u*)p); }
 #endif
 SKY_DEV sky_u64 sky_ld64a(const void* p) { sky_u64 v; __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 8); return v; }
 SKY_DEV void sky_st64a(void* p, sky_u64 v) { __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, 8); }

@@ -82,7 +82,6 @@ SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
 SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return (uint32_t)((sky_u64)(a & 0xFFFFFFu) * (sky_u64)(b & 0xFFFFFFu)); }
 SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return sky_mul24(a, b) + c; }
-SKY_DEV uint32_t sky_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((sky_u64)hi) << 32) | lo) >> (8u * (sh & 3u))); }
 SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) {      // v_perm_b32 (selectors 0-7 and 0x0c only: what the kernels use)
     const sky_u64 both = ((sky_u64)hi << 32) | lo;
     uint32_t r = 0;
@@ -96,7 +95,6 @@ SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) {      // v_pe
 SKY_DEV uint32_t sky_shl1_lt(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a < b ? 1u : 0u); }
 SKY_DEV uint32_t sky_shl1_eq(uint32_t bits, uint32_t a, uint32_t b) { return bits + bits + (a == b ? 1u : 0u); }
 SKY_DEV void sky_keep(uint32_t) {}
-SKY_DEV void sky_glds16(const uint8_t* g, uint8_t* lds_wave_base) { memcpy(lds_wave_base + 16 * sky_lane(), g, 16); }
 SKY_DEV uint32_t sky_undef32() { return 0xDEADBEEFu; }
 SKY_DEV uint32_t sky_opaque(uint32_t v) { return v; }
 #define SKY_RESTRICT
