@@ -97,6 +97,13 @@ def run_lz4d():
             frame = emulib.process([data], flags=1)[0][0]
             rc, outs, status = emulib.decompress([frame], [n], guard="end")
             assert rc == 0 and outs[0] == data, (n, name)
+    # frames built sequence by sequence (every path of the batch decoder, tests/_crafted_frames.py), whole and corrupted
+    from tests._crafted_frames import crafted_frames
+    crafted = crafted_frames(2)
+    for name, (frame, data) in crafted.items():
+        for guard in ("end", "start"):
+            rc, outs, status = emulib.decompress([frame], [len(data)], guard=guard)
+            assert rc == 0 and status == [0] and outs[0] == data, (name, guard, rc, status)
     # corrupted frames: never a crash, never a byte outside the buffers, and the same accept/reject decision and the same
     # bytes as liblz4 (lz4.frame.decompress, gateway_receiver.py:196)
     rng = np.random.default_rng(20240917)
@@ -106,6 +113,7 @@ def run_lz4d():
         d = synth.gen_class(cls, 3000 + 500 * i, synth.rng_for(5, i)).tobytes()
         bases += [(d, ref.lz4f_compress(d)), (d, ref.lz4f_compress_port(d))]
     bases.append((bytes(70000), ref.lz4f_compress(bytes(70000))))
+    bases += [(d, f) for f, d in (crafted[k] for k in ("length_field_edges", "short_offsets", "three_byte_sequences", "long_fields"))]
     agree = 0
     for it in range(200):
         d, f = bases[it % len(bases)]

@@ -12,6 +12,7 @@
 #include "md5_kernel.inc"
 #include "frame_kernel.inc"
 #include "lz4d_kernel.inc"
+extern "C" uint32_t sky_d_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // see SKY_D_STAT
 #ifdef SKY_WITH_CDC
 #include "gear_kernel.inc"
 #endif

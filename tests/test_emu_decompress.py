@@ -154,3 +154,23 @@ def test_emu_linked_frames_with_many_and_chained_matches():
     rc, outs, status = emulib.decompress(frames, [len(c) for c in cases])
     assert rc == 0 and status == [0] * len(cases)
     assert outs == cases
+
+
+def test_emu_decode_crafted_sequence_streams():
+    """Frames built sequence by sequence (tests/_crafted_frames.py): length fields around every nibble / extension-byte boundary, 64 three-byte sequences per
+    window, batches above the LDS staging size, matches that begin before a batch and end inside it, fields longer than a window, a frame without content size."""
+    from tests._crafted_frames import crafted_frames
+    import ctypes
+    cases = crafted_frames(1)
+    names = list(cases)
+    stats = (ctypes.c_uint32 * 8).in_dll(emulib.lib(), "sky_d_stats")
+    for i in range(8):
+        stats[i] = 0
+    rc, outs, status = emulib.decompress([cases[k][0] for k in names], [len(cases[k][1]) for k in names])
+    assert rc == 0, dict(zip(names, status))
+    for k, o, s in zip(names, outs, status):
+        assert s == 0 and o == cases[k][1], k
+    # the frames reached every path of the batch decoder (skyplane_amd/csrc/lz4d_kernel.inc, SKY_D_STAT): batches put together in LDS, batches too big for it,
+    # batches with a match across their start, the 64th sequence of a window, sequences walked byte by byte inside and outside the window, copies from the batch itself
+    seen = dict(zip(("batches", "staged", "too_big", "straddle", "drop64", "walk_one", "serial_seq", "inside"), list(stats)))
+    assert all(v > 0 for v in seen.values()), seen

@@ -160,3 +160,18 @@ def test_decode_linked_frames_with_many_and_chained_matches(ctx):
     for _ in range(2):
         outs = ctx.decompress_batch(frames, [len(c) for c in cases])
         assert outs == cases
+
+
+def test_decode_crafted_sequence_streams(ctx):
+    """Frames built sequence by sequence (tests/_crafted_frames.py; the emulator test of the same name asserts that they reach every path of the batch
+    decoder): length fields around every nibble / extension-byte boundary, 64 three-byte sequences per window, batches above the LDS staging size, matches
+    that begin before a batch and end inside it, fields longer than a window, a frame without content size -- alone, and all in one launch."""
+    from tests._crafted_frames import crafted_frames
+    for seed in (1, 2, 3):
+        cases = crafted_frames(seed)
+        names = list(cases)
+        outs = ctx.decompress_batch([cases[k][0] for k in names], [len(cases[k][1]) for k in names])
+        for k, o in zip(names, outs):
+            assert o == cases[k][1], (seed, k)
+        for k in names:
+            assert ctx.decompress_batch([cases[k][0]], [len(cases[k][1])])[0] == cases[k][1], (seed, k)
