@@ -21,9 +21,11 @@ def _ext(x):
     return bytes(out)
 
 
-def encode_block(seqs, last_literals):
-    """seqs: [(literals: bytes, offset: int, match_len >= 4)], then the block's final literal-only sequence.  Returns (compressed, decoded)."""
-    comp, out = bytearray(), bytearray()
+def encode_block(seqs, last_literals, history=b""):
+    """seqs: [(literals: bytes, offset: int, match_len >= 4)], then the block's final literal-only sequence.  Returns (compressed, decoded).
+    history: what a block-linked frame's earlier blocks decoded to (a match may reach up to 65535 bytes back into it)."""
+    comp, out = bytearray(), bytearray(history[-65535:])
+    h = len(out)
     for lit, off, ml in seqs:
         assert ml >= 4 and 1 <= off <= len(out) + len(lit) and off <= 65535
         comp.append((min(len(lit), 15) << 4) | min(ml - 4, 15))
@@ -41,20 +43,20 @@ def encode_block(seqs, last_literals):
         comp += _ext(len(last_literals))
     comp += last_literals
     out += last_literals
-    return bytes(comp), bytes(out)
+    return bytes(comp), bytes(out[h:])
 
 
-def frame_of(blocks, sized=True):
-    """blocks: [(compressed, decoded)] with every block but the last decoding to exactly 64 KiB.  Block-independent frame, no checksums."""
+def frame_of(blocks, sized=True, linked=False):
+    """blocks: [(compressed, decoded)] with every block but the last decoding to exactly 64 KiB.  No checksums; block-independent unless `linked`."""
     total = sum(len(d) for _, d in blocks)
-    flg = 0x60 | (0x08 if sized else 0)
+    flg = 0x40 | (0 if linked else 0x20) | (0x08 if sized else 0)
     desc = bytes((flg, 0x40)) + (total.to_bytes(8, "little") if sized else b"")
     hdr = b"\x04\x22\x4d\x18" + desc + bytes(((ref.xxh32(desc) >> 8) & 0xFF,))
     body = b"".join(len(c).to_bytes(4, "little") + c for c, _ in blocks)
     return hdr + body + bytes(4), b"".join(d for _, d in blocks)
 
 
-def _fill_block(rng, gen):
+def _fill_block(rng, gen, history=b""):
     """Run `gen(state)` -> (literals, offset, match_len) until the block holds exactly 64 KiB; the last 5+ bytes are literals (the format's end rule)."""
     seqs, n = [], 0
     while True:
@@ -63,7 +65,7 @@ def _fill_block(rng, gen):
             break
         seqs.append((lit, off, ml)); n += len(lit) + ml
     tail = rng.integers(0, 256, BLOCK - n, dtype=np.uint8).tobytes()
-    return encode_block(seqs, tail)
+    return encode_block(seqs, tail, history)
 
 
 def crafted_frames(seed=0):
@@ -110,6 +112,24 @@ def crafted_frames(seed=0):
     blocks.append(encode_block(seqs, rnd(9)))
     cases["random_sequences"] = frame_of(blocks)
     cases["random_sequences_unsized"] = frame_of(blocks, sized=False)
+    # 5b. the same in a block-LINKED frame (what lz4.frame.compress makes by default): offsets reach into the previous block
+    def g5l(hist):
+        def g(n):
+            lit, off, ml = g5(n)
+            if hist and rng.random() < 0.5:
+                off = int(rng.integers(1, min(n + len(lit) + hist, 65535) + 1))
+            return lit, off, ml
+        return g
+    lblocks, hist = [], b""
+    for _ in range(3):
+        c, d = _fill_block(rng, g5l(len(hist)), hist)
+        lblocks.append((c, d)); hist = (hist + d)[-65535:]
+    seqs, n = [], 0
+    g = g5l(len(hist))
+    for _ in range(100):
+        lit, off, ml = g(n); seqs.append((lit, off, ml)); n += len(lit) + ml
+    lblocks.append(encode_block(seqs, rnd(11), hist))
+    cases["random_sequences_linked"] = frame_of(lblocks, linked=True)
     # 6. one long literal run and one long match that do not fit a window, and a block of literals only
     cases["long_fields"] = frame_of([encode_block([(rnd(5000), 4000, 30000), (b"", 1, 20000), (rnd(3), 25000, 4)], rnd(BLOCK - 5000 - 30000 - 20000 - 3 - 4)),
                                      encode_block([], rnd(777))])
