@@ -7,9 +7,13 @@ One "step" = one pass of the hot path (LZ4 frame + MD5 per 8 MiB chunk) over a d
               sparse), 16384 chunks = 128 GiB per GPU, processed as two resident halves.  N independent ranks, chunk i of
               the node's queue on rank i % N, no collective on the data path (weak scaling).
 Inputs are resident in HBM before the timed region; PCIe is excluded (DESIGN.md has the host-inclusive rate).
-Rank 0 prints ONE JSON line.  After the timed region every digest of the step is checked against hashlib and a sample
-of frames against liblz4 (the reference's decoder), on a pool of CPU processes forked before HIP is initialised; the
-same pool times the reference's CPU path (cpu_baseline: one PROCESS per schedulable core).
+Rank 0 prints ONE JSON line.  After the timed region every digest of the step is checked against hashlib and every
+frame still resident against liblz4 (the reference's decoder), on a pool of CPU processes forked before HIP is
+initialised; the same pool times the reference's CPU path (cpu_baseline: one PROCESS per schedulable core).
+The default 1-GPU run (no workload flags) also carries a `secondary` object: short verified runs of configs[2]
+(`--cdc`) and of the configs[3] stream on one GPU (`--stream mixed --chunks 16384`), each its own process after the
+headline's device memory has been given back, each with the same roofline / verified fields (`--no-secondary` skips them).
+Progress goes to stderr as `[bench +seconds] ...` lines (a heartbeat: the JSON line is the only thing on stdout).
 
 --context emu (tests only): the shipping kernel source under the CPU SIMT emulator, tensors on the host, gloo instead of
 RCCL -- that is how tests/test_host_operator.py runs this file's multi-rank logic with world_size 2 on a box without GPUs.
@@ -170,6 +174,37 @@ class EmuContext:
         pass
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """heartbeat on stderr (stdout carries the one JSON line): a driver that waits on a long run sees where it is"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def run_secondary(extra, steps, warmup):
+    """One of the other single-GPU configurations as its own process (own HIP context, own CPU pool): returns its JSON line as a dict, or the reason
+    it has none.  The same file, the same verification, fewer steps."""
+    import subprocess
+
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary"] + extra
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+        line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": f"exit code {p.returncode}", "command": " ".join(cmd[1:])}
+        r = json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout after 600 s", "command": " ".join(cmd[1:])}
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_step", "verified")
+    out = {k: r[k] for k in keep if k in r}
+    out["command"] = "python bench.py " + " ".join(cmd[2:])
+    out["run_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher around it: re-execute this very command line as N ranks of one node under
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 -- the container's hostname may not resolve)."""
@@ -191,8 +226,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU per step (0 = the configuration's own: 8192 at 1 GPU, 16384 at N GPUs)")
     ap.add_argument("--unit-mib", type=int, default=256)
-    ap.add_argument("--max-batch", type=int, default=1024, help="chunks per LZ4 launch (block scratch = 8.06 MiB per chunk; 1024: the frame gather of the last "
-                                                                "sub-batch, the one thing of a step that nothing overlaps, is half as long as with 2048)")
+    ap.add_argument("--max-batch", type=int, default=1024, help="chunks per LZ4 launch on the block-queue path (device-resident batches below 2 chunks per CU and "
+                                                                "SKYHIP_FRAMES_MIN=0 runs; block scratch = 8.06 MiB per chunk); the default run writes frames in place and never uses it")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] / configs[3]-on-one-GPU runs appended to the default 1-GPU line")
+    ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", choices=["auto", "silesia", "mixed"], default="auto",
                     help="auto = silesia (configs[1]) on one GPU, mixed (configs[3]) on several")
@@ -241,6 +278,7 @@ def main():
         _G["arena"] = [np.frombuffer(mmap.mmap(-1, round_n * bound_h), np.uint8) for _ in range(2)]
     pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None
 
+    log(f"host unit of {unit_bytes >> 20} MiB generated, CPU pool of {pool_n} forked")
     import torch  # noqa: E402  (imported before libskyhip so both share one HIP runtime; no device touched before the fork above)
 
     if emu:
@@ -258,6 +296,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    log("torch imported" + (f", process group of {world} up" if world > 1 else ""))
     from skyplane_amd import hip_ops
 
     bound = 15 + cb + 4 * ((cb + 65535) // 65536) + 4 if emu else hip_ops.frame_bound(cb)
@@ -270,23 +309,33 @@ def main():
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         frames_min = int(os.environ.get("SKYHIP_FRAMES_MIN", 2 * cus))      # (the library's rule: skyhip.hip)
 
-        def need(n, d):
+        def need(n, d, shared=True):
             in_place = frames_min > 0 and n >= frames_min
             scratch = 0 if in_place else int(2.5 * args.max_batch * 128 * 66048)      # block scratch, double-buffered, only on the block-queue path
-            return n * cb + d * (n // halves) * stride + d * scratch + (6 << 30)
+            return n * cb + d * (n // (halves if shared else 1)) * stride + d * scratch + (6 << 30)      # (6 GiB: the library's metadata, RCCL's buffers, torch's cache)
 
         if depth > 1 and need(n_chunks, depth) > free_b:
             depth = 1
         while n_chunks > 64 and need(n_chunks, depth) > free_b:
             n_chunks //= 2
+        # every chunk of a step gets its own frame slot when that fits (include/skyhip.h: frame regions of one call must not overlap); only when HBM is too
+        # small for that do the halves of a step share slots (chunk i + n/2 over chunk i's: the queue hands chunks out in index order, a slot's first
+        # frame is complete thousands of chunks before its second one is started -- and every resident frame is decoded and compared after the run)
+        share_slots = halves > 1 and need(n_chunks, depth, shared=False) > free_b
         in_place = frames_min > 0 and n_chunks >= frames_min
     else:
         in_place = False
+        share_slots = halves > 1
     if world > 1:   # every rank processes the same number of chunks (weak scaling: value = world x chunks x bytes / time)
         nc = torch.tensor([n_chunks], dtype=torch.int64, device=dev)
         dist.all_reduce(nc, op=dist.ReduceOp.MIN)
         n_chunks = int(nc.item())
+    if world > 1:
+        sh = torch.tensor([int(share_slots)], dtype=torch.int64, device=dev)
+        dist.all_reduce(sh, op=dist.ReduceOp.MAX)
+        share_slots = bool(sh.item())
     n_half = n_chunks // halves
+    n_slots = n_half if share_slots else n_chunks
 
     # ---- the resident stream: the unit tiled and rotated on the device.  This rank holds the chunks rank, rank + world, ... of
     # the node's queue (chunk_index % n_gpus); with a synthetic queue that is a rank-dependent rotation per tile. ----
@@ -305,7 +354,7 @@ def main():
             tile = tile ^ (t & 0xFF)      # keep the unit's internal duplicate structure, make tiles mutually distinct
         d_in[lo:hi] = tile
     del d_unit
-    d_outs = [torch.empty(n_half * stride, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    d_outs = [torch.empty(n_slots * stride, dtype=torch.uint8, device=dev) for _ in range(depth)]
     d_out = d_outs[0]
     if not emu:
         torch.cuda.synchronize(dev)
@@ -313,9 +362,9 @@ def main():
 
     in_off = np.arange(n_chunks, dtype=np.uint64) * cb
     in_len = np.full(n_chunks, cb, np.uint64)
-    out_off = np.arange(n_half, dtype=np.uint64) * stride
-    out_cap = np.full(n_half, stride, np.uint64)
-    out_off_all, out_cap_all = np.tile(out_off, halves), np.tile(out_cap, halves)
+    out_off = np.arange(n_slots, dtype=np.uint64) * stride
+    out_cap = np.full(n_slots, stride, np.uint64)
+    out_off_all, out_cap_all = (np.tile(out_off, halves), np.tile(out_cap, halves)) if share_slots else (out_off, out_cap)
 
     if emu:
         ctxs = [EmuContext()]
@@ -330,9 +379,8 @@ def main():
     def step(lane=0):
         if args.cdc:
             ctxs[lane].dedup_reset()      # every step sees the stream for the first time
-        # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the compressor;
-        # with two resident halves the second half's frames take over the first half's slots (the chunk queue hands chunks out in index order:
-        # a slot's first frame is complete thousands of chunks before its second one is started)
+        # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the compressor
+        # (out_off_all: a slot per chunk, or -- share_slots, when HBM is short -- the second half's frames over the first half's)
         lasts[lane]["out_len"], lasts[lane]["md5"] = ctxs[lane].process_device(p_in, in_off, in_len, p_outs[lane], out_off_all, out_cap_all, flags)
 
     def run_steps(k_steps):
@@ -366,11 +414,13 @@ def main():
         if not emu:
             torch.cuda.synchronize(dev)
 
+    log(f"stream resident ({n_chunks} chunks of {cb} B per rank, {halves} half(s), depth {depth}, setup {gen_s:.1f}s); warmup")
     run_steps(args.warmup)
     if depth > 1 and args.warmup < depth:
         run_steps(depth - args.warmup)      # every lane's context has run once before the clock starts
     for c_ in ctxs:
         c_.reset_timing()
+    log(f"timed region: {args.steps} steps")
     _local, elapsed = shard.timed_region(lambda: run_steps(args.steps), 1, dist=dist, sync=sync)      # EXACTLY args.steps steps between barrier + synchronize, MAX over ranks
     tms = [c_.timing() for c_ in ctxs]
 
@@ -397,6 +447,11 @@ def main():
     # ---- verification, outside the timed region: every digest of the last step, a sample of the frames of its last half ----
     verified = {"digests": 0, "frames": 0}
     if args.verify != "none":
+        # what the check costs on this host (hashlib ~0.55 GiB/s and liblz4 decode ~2 GiB/s per process): said BEFORE it starts, so that a long
+        # silence on stdout is never a mystery
+        nv = n_chunks if args.verify == "full" else 64
+        est = nv * cb / 2**30 / (0.5 * pool_n) + ((n_half if share_slots else n_chunks) if args.verify == "full" else 24) * cb / 2**30 / (1.5 * pool_n)
+        log(f"timed region done ({elapsed / args.steps * 1e3:.1f} ms per step); verifying {nv} digests + frames on {pool_n} processes, about {est:.0f} s")
         idx = list(range(n_chunks)) if args.verify == "full" else sorted(set(np.linspace(0, n_chunks - 1, 64).astype(int).tolist()))
         spans = [(idx[k], idx[k] + 1) for k in range(len(idx))] if args.verify != "full" else [(lo, min(lo + 16, n_chunks)) for lo in range(0, n_chunks, 16)]
         for lo, digs in pool.imap_unordered(_w_md5, [(lo, hi, rots, args.cdc) for lo, hi in spans], chunksize=1):
@@ -405,7 +460,9 @@ def main():
         verified["digests"] = len(idx)
         # every frame still resident (all of them; with two halves the second half, whose frames replaced the first's in the slots): D2H into
         # a shared arena round by round (double buffered), decoded and compared by the pool while the next round is copied
-        js = list(range(n_half)) if args.verify == "full" else sorted(set(np.linspace(0, n_half - 1, 24).astype(int).tolist()))
+        n_res = n_half if share_slots else n_chunks      # frames still resident: every one, or (shared slots) the last half's
+        first_res = n_chunks - n_res
+        js = list(range(n_res)) if args.verify == "full" else sorted(set(np.linspace(0, n_res - 1, 24).astype(int).tolist()))
         arenas = [torch.from_numpy(a) for a in _G["arena"]]
         if not emu:
             for a in arenas:      # page-lock the arenas for asynchronous D2H (best effort: pageable copies work too)
@@ -423,9 +480,9 @@ def main():
             which = (r0 // round_n) & 1
             items, o = [], 0
             for j in js[r0:r0 + round_n]:
-                i = (halves - 1) * n_half + j
+                i = first_res + j
                 ln = int(out_len[i])
-                arenas[which][o:o + ln].copy_(d_out[int(out_off[j]):int(out_off[j]) + ln], non_blocking=True)
+                arenas[which][o:o + ln].copy_(d_out[int(out_off_all[i]):int(out_off_all[i]) + ln], non_blocking=True)
                 items.append((i, o, ln)); o += ln
             sync()
             if pending is not None:
@@ -460,7 +517,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cfg_id}: {world} MI355X, {cb >> 20} MiB chunks, LZ4 frame + MD5 HIP kernels, {sdesc}; "
-                                   f"{n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks per step in {halves} resident half(s), {unit_bytes >> 20} MiB unit tiled + rotated",
+                                   f"{n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks per step in {halves} resident half(s){' sharing frame slots' if share_slots and halves > 1 else ''}, {unit_bytes >> 20} MiB unit tiled + rotated",
                        "chunk_bytes": cb, "chunks_per_gpu": n_chunks, "lz4_ratio": round(n_chunks * cb / comp_bytes, 4),
                        "sharding": "chunk i of the node's queue on rank i % N, no collective on the data path" if world > 1 else "single GPU", "max_batch": args.max_batch,
                        "steps_in_flight": depth, "lz4_path": "frames written in place, one launch per step" if in_place else "block queue + frame gather, sub-batches of max_batch"},
@@ -520,12 +577,25 @@ def main():
             g0 = int(prefix[n_s])
             res["config"]["duplicate_bytes_fraction_same_sample_gpu"] = round(float(seg_len[:g0][dup[:g0]].sum() / seg_len[:g0].sum()), 4)
         if want_cpu:
+            log(f"cpu_baseline on {cores} processes")
             res["cpu_baseline"] = cpu_baseline(pool, cores, quota, rots, 12.0 if world == 1 else 6.0)
-        print(json.dumps(res), flush=True)
     if pool is not None:
         pool.close(); pool.join()
     for c_ in ctxs:
         c_.close()
+    if rank == 0:
+        default_run = world == 1 and not emu and not args.cdc and args.stream == "auto" and args.chunks == 0 and cb == synth.CHUNK_BYTES
+        if default_run and not args.no_secondary:
+            # the other single-GPU configurations, in front of whoever runs the default command: each in its own process, after this one's
+            # stream and frame slots have gone back to the device
+            del d_in, d_outs, d_out, tile
+            torch.cuda.empty_cache()
+            res["secondary"] = {}
+            for key, extra in (("configs[2]", ["--cdc"]), ("configs[3] stream on one GPU", ["--stream", "mixed", "--chunks", "16384"])):
+                log(f"secondary run {key}: bench.py {' '.join(extra)} --steps {args.secondary_steps}")
+                res["secondary"][key] = run_secondary(extra, args.secondary_steps, 1)
+        log("done")
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

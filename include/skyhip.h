@@ -53,14 +53,14 @@ typedef struct skyhip_ctx skyhip_ctx;   /* opaque: owns device scratch, streams,
 
 /* Per-kernel device time (HIP events on the library's own streams) accumulated since the last reset. */
 typedef struct skyhip_timing {
-    double lz4_ms;        /* sky_lz4_compress: the dominant kernel */
+    double lz4_ms;        /* sky_lz4s_frames (large device-resident batches) / sky_lz4s_compress (block queue): the dominant kernel */
     double layout_ms;     /* sky_frame_layout */
     double gather_ms;     /* sky_frame_gather */
     double md5_ms;        /* sky_md5_chunks */
     double cdc_ms;        /* gear candidate + cut selection + segment fingerprints + dedup */
     uint64_t lz4_launches;
     uint64_t lz4_in_bytes;   /* raw bytes the LZ4 kernel consumed */
-    uint64_t lz4_out_bytes;  /* bytes it wrote to its block slots... (frame bytes incl. headers) */
+    uint64_t lz4_out_bytes;  /* frame bytes produced (headers, size words and EndMark included) */
     uint64_t md5_launches;
     uint64_t md5_in_bytes;
 } skyhip_timing;
@@ -109,7 +109,8 @@ int  skyhip_host_unregister(skyhip_ctx* ctx, void* p);
  * A batch of at least two chunks per CU of the device (environment SKYHIP_FRAMES_MIN at skyhip_create: another threshold, 0 = never) is compressed by ONE
  * launch in which a workgroup takes a whole chunk at a time and writes its frame in place -- header, block size words, blocks, EndMark --; smaller
  * batches go block by block through scratch slots and a gather pass.  Both produce the same bytes.  Frame regions [out_off[i], out_off[i] + out_cap[i])
- * must not overlap unless the caller accepts that the chunk started later wins (chunks are started in index order).  Two contexts of one process may
+ * must NOT overlap: the in-place launch has no ordering between workgroups (chunks are STARTED in index order, nothing says when one is finished), so two
+ * chunks that share a region may leave a mixture of both frames.  Two contexts of one process may
  * call this concurrently (one host thread each): their whole-chip compressor launches are queued back to back on the device, their digest kernels overlap. */
 int  skyhip_process_device(skyhip_ctx* ctx, int n,
                            const void* d_in, const uint64_t* in_off, const uint64_t* in_len,

@@ -123,15 +123,20 @@ class _Bounds:
         self.touched: Dict[Tuple[int, int], float] = {}
         self.nbytes: Dict[Tuple[int, int], int] = {}
         self.evicted: Dict[Tuple[int, int], float] = {}      # groups the byte budget took although their lane had not moved on (bounded: see over_budget)
+        self.lane_touch: Dict[int, float] = {}               # last use of any group of a lane (is_live in O(1): ADVICE r4, it scanned `touched` per key)
         self.over_budget_live = False
+
+    def touch(self, key, now=None):
+        now = time.monotonic() if now is None else now
+        self.touched[key] = now
+        self.lane_touch[key[0]] = now
 
     def is_live(self, key, now=None) -> bool:
         top = self.lane_max.get(key[0])
         if top is None or key[1] + self.keep_epochs <= top:
             return False
         now = time.monotonic() if now is None else now
-        lane_touch = max((t for k, t in self.touched.items() if k[0] == key[0]), default=0.0)
-        return now - lane_touch <= self.live_grace_s
+        return now - self.lane_touch.get(key[0], 0.0) <= self.live_grace_s
 
     def admit(self, lane: int, epoch: int) -> List[Tuple[int, int]]:
         """Called (under the store's lock) before (lane, epoch) is written; returns the groups to drop because of it."""
@@ -142,8 +147,10 @@ class _Bounds:
         if top is None or epoch > top:
             self.lane_max[lane] = epoch
             drop = [k for k in self.nbytes if k[0] == lane and k[1] + self.keep_epochs <= epoch]
+            for k in [k for k in self.evicted if k[0] == lane and k[1] + self.keep_epochs <= epoch]:
+                del self.evicted[k]                  # the lane moved past it: nobody may reference it any more
         now = time.monotonic()
-        self.touched[(lane, epoch)] = now
+        self.touch((lane, epoch), now)
         self.nbytes.setdefault((lane, epoch), 0)
         if self.idle_s > 0:
             drop += [k for k, t in self.touched.items() if now - t > self.idle_s and k not in drop and k != (lane, epoch)]
@@ -166,8 +173,11 @@ class _Bounds:
         self.over_budget_live = total > self.max_bytes
         return drop
 
-    def check_not_evicted(self, lane: int, epoch: int):
-        if (lane, epoch) in self.evicted:
+    def check_not_evicted(self, lane: int, epoch: int, missing: bool = True):
+        """Raised only for a reference that is actually MISSING from a group the budget took (the mark was sticky -- a lane that went silent,
+        was evicted and then resumed in the same epoch re-created the group, and every later chunk of that epoch failed although all it referenced
+        had arrived after the eviction)."""
+        if missing and (lane, epoch) in self.evicted:
             raise StoreEvicted(f"segments of lane {lane:#x} epoch {epoch} were evicted by the destination's byte budget ({self.max_bytes} bytes): "
                                "raise the segment store's max_bytes or lower the sender's dedup_epoch_bytes")
 
@@ -176,6 +186,7 @@ class _Bounds:
         self.nbytes.pop(key, None)
         if not any(k[0] == key[0] for k in self.nbytes):
             self.lane_max.pop(key[0], None)          # the lane is gone: a later transfer may reuse the id from any epoch
+            self.lane_touch.pop(key[0], None)
 
 
 class SegmentStore:
@@ -225,11 +236,12 @@ class SegmentStore:
 
     def get_many(self, lane: int, epoch: int, fps: List[bytes]) -> List[Optional[Tuple[bytes, int, int]]]:
         with self._lock:
-            self._b.check_not_evicted(lane, epoch)
             d = self._segs.get((lane, epoch), {})
             if d:
-                self._b.touched[(lane, epoch)] = time.monotonic()
-            return [d.get(fp) for fp in fps]
+                self._b.touch((lane, epoch))
+            out = [d.get(fp) for fp in fps]
+            self._b.check_not_evicted(lane, epoch, missing=any(h is None for h in out))
+            return out
 
     def cleanup(self):
         with self._lock:
@@ -369,17 +381,17 @@ class FileSegmentStore:
 
     def get_many(self, lane: int, epoch: int, fps: List[bytes]):
         with self._lock:
-            self._b.check_not_evicted(lane, epoch)
             d = self._idx.get((lane, epoch), ({}, 0))[0]
             if any(fp not in d for fp in fps):
                 d = self._refresh(lane, epoch)
             if d:
-                self._b.touched[(lane, epoch)] = time.monotonic()
+                self._b.touch((lane, epoch))
             out = []
             for fp in fps:
                 h = d.get(fp)
                 m = None if h is None else self._map(lane, epoch, h[0])
                 out.append(None if m is None else (m, h[1], h[2]))
+            self._b.check_not_evicted(lane, epoch, missing=any(h is None for h in out))
             return out
 
     def cleanup(self):

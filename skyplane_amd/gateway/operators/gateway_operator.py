@@ -237,15 +237,26 @@ class GatewayHipCompress(GatewayOperator):
 
     def _writer(self, ctx, largest: int = 0) -> "shm_arena.ArenaWriter":
         """This lane's arena (created on first use, page-locked through the lane's context when that is a real device).  `largest` = the largest chunk of
-        the batch at hand: it sizes the slots when arena_slot_bytes was left at 0."""
+        the batch at hand: it sizes the slots when arena_slot_bytes was left at 0.  A lane whose FIRST batch held only small chunks (small objects, a
+        file's short tail) is not stuck with small slots for the rest of the transfer: when a larger chunk shows up the lane opens a new arena
+        sized for it -- and says so -- while the old one stays mapped until its published slots have been sent."""
+        fb = ctx.frame_bound if hasattr(ctx, "frame_bound") else (lambda n: 15 + n + 4 * ((n + 65535) // 65536) + 4)
         w = getattr(self._tls, "writer", None)
-        if w is None:
-            fb = ctx.frame_bound if hasattr(ctx, "frame_bound") else (lambda n: 15 + n + 4 * ((n + 65535) // 65536) + 4)
-            bound = self.arena_slot_bytes or (fb(min(max(largest, 1 << 16), self.max_chunk_bytes)) + 4095) & ~4095
-            tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
-            w = shm_arena.ArenaWriter(self.chunk_store.get_chunk_file_path("x").parent, tag, bound, self.arena_slots or 2 * self.max_batch)
-            shm_arena.register_once(w.arena, ctx)
-            self._tls.writer = w
+        need = (fb(min(max(largest, 1 << 16), self.max_chunk_bytes)) + 4095) & ~4095
+        if w is not None and (self.arena_slot_bytes or need <= w.arena.slot_bytes):
+            return w
+        gen = getattr(self._tls, "writer_gen", 0)
+        if w is not None:
+            print(f"[{self.handle}] arena slots of {w.arena.slot_bytes} bytes (sized by this lane's first batch) are too small for a chunk of {largest} bytes: "
+                  f"new arena with slots of {need} bytes", flush=True)
+            old = getattr(self._tls, "old_writers", [])
+            old.append(w)
+            self._tls.old_writers = old
+        bound = self.arena_slot_bytes or need
+        tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}" + (f"_g{gen}" if gen else "")
+        w = shm_arena.ArenaWriter(self.chunk_store.get_chunk_file_path("x").parent, tag, bound, self.arena_slots or 2 * self.max_batch)
+        shm_arena.register_once(w.arena, ctx)
+        self._tls.writer, self._tls.writer_gen = w, gen + 1
         return w
 
     def _read_chunks(self, chunk_reqs: List[ChunkRequest], ctx):
@@ -489,12 +500,13 @@ class GatewayHipCompress(GatewayOperator):
         """Every lane of this worker process has left its loop."""
 
     def worker_exit(self, worker_id: int):
-        w = getattr(self._tls, "writer", None)
-        if w is not None:
-            self._tls.writer = None
+        for w in [getattr(self._tls, "writer", None)] + list(getattr(self._tls, "old_writers", [])):
+            if w is None:
+                continue
             shm_arena.forget(w.arena)
             # (the file stays while a pointer into it may still be waiting for its sender; the chunk directory is wiped at daemon start)
             w.arena.close(unlink=not any(o is not None and o.exists() for o in w._owner))
+        self._tls.writer, self._tls.old_writers = None, []
         if self._ctx is not None:
             self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
@@ -576,6 +588,10 @@ class GatewayHipDecompress(GatewayHipCompress):
         if len(li) and cid not in self._put_done:      # once per chunk: a chunk that waits for a reference comes back here many times
             store.put_chunk(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in li], lit_start[li], lens[li], lit.tobytes())
             self._put_done.add(cid)
+        if store.over_budget_live and not getattr(self, "_warned_over_budget", False):
+            self._warned_over_budget = True      # said once: the budget never evicts what the sender may still reference, so the store outgrows it
+            print(f"[{self.handle}] segment store holds more than its byte budget in LIVE (lane, epoch) groups (bounded by lanes x keep_epochs x the "
+                  "sender's dedup_epoch_bytes): raise the store's max_bytes or lower dedup_epoch_bytes", flush=True)
         ri = np.nonzero(~is_lit)[0]
         hits = store.get_many(rec.lane, rec.epoch, [fpblob[16 * k:16 * k + 16] for k in ri]) if len(ri) else []
         for k, h in zip(ri, hits):

@@ -6,12 +6,14 @@ the receiver (gateway_receiver.py:142-237) and chunk.py stay untouched.  INTEGRA
 from __future__ import annotations
 
 import array
+import errno
 import fcntl
 import os
 import termios
 import time
+import weakref
 from collections import deque
-from typing import Dict, Optional, Tuple
+from typing import Optional, Tuple
 
 from skyplane_amd.chunk import ChunkRequest, WireProtocolHeader
 from skyplane_amd.gateway import shm_arena, sidecar
@@ -46,7 +48,17 @@ class _SockLedger:
         self.pending = deque()         # (byte count at the end of the frame, pointer path) in send order
 
 
-_LEDGERS: Dict[int, _SockLedger] = {}
+# Keyed by the socket OBJECT, weakly: a ledger keyed by sock.fileno() outlived its socket, and the reconnect that got the same descriptor
+# number inherited the dead connection's byte count and pending list -- the retry of a chunk then freed its slot on the strength of bytes the OLD
+# connection had counted.  A ledger now dies with its socket (or with `forget`), whatever number the kernel hands out next.
+_LEDGERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _ledger(sock, create: bool = False) -> Optional[_SockLedger]:
+    led = _LEDGERS.get(sock)
+    if led is None and create:
+        led = _LEDGERS[sock] = _SockLedger()
+    return led
 
 
 def _unacked(sock) -> int:
@@ -62,30 +74,53 @@ def _unlink_quiet(path):
         pass
 
 
+def _still_referenced(path, but_not) -> bool:
+    """Is `path` (a pointer file = an arena slot) still waiting for acknowledgement on ANOTHER live socket?  A chunk that is sent again after a
+    connection died has one entry per attempt; the slot goes back when the last of them is acknowledged -- or forgotten."""
+    for sk, led in list(_LEDGERS.items()):
+        if sk is not but_not and any(q == path for _c, q in led.pending):
+            return True
+    return False
+
+
 def release_acked(sock) -> int:
     """Unlink the pointer files of this socket's released frames whose bytes the peer has acknowledged; returns how many are still waiting."""
-    led = _LEDGERS.get(sock.fileno())
+    led = _ledger(sock)
     if led is None or not led.pending:
         return 0
     try:
+        if sock.fileno() < 0:              # closed: what the kernel still has queued cannot be asked about any more -- wait for forget()
+            return len(led.pending)
         acked = led.sent - _unacked(sock)
-    except OSError:                        # not a TCP socket (a test's socketpair): nothing is ever retransmitted, delivered = copied
-        acked = led.sent
+    except OSError as e:
+        if e.errno in (errno.EBADF, errno.ENOTCONN, errno.EPIPE, errno.ECONNRESET):      # the socket is dead: what it had in flight is not acknowledged and never will be
+            return len(led.pending)
+        acked = led.sent                   # not a TCP socket (a test's socketpair): nothing is ever retransmitted, delivered = copied
     while led.pending and led.pending[0][0] <= acked:
-        _unlink_quiet(led.pending.popleft()[1])
+        path = led.pending.popleft()[1]
+        if not any(q == path for _c, q in led.pending) and not _still_referenced(path, sock):      # (the same chunk sent twice: the later entry decides)
+            _unlink_quiet(path)
     return len(led.pending)
+
+
+def forget(sock) -> int:
+    """Call on EVERY close or error path of a socket that sent frames with ``release=True``: drops its ledger WITHOUT unlinking anything -- what was
+    in flight on a dead connection was not acknowledged, its chunks will be sent again (same pointer file, another socket) and released there.
+    Returns how many frames were still pending."""
+    led = _LEDGERS.pop(sock, None)
+    return len(led.pending) if led else 0
 
 
 def drain_releases(sock, timeout: float = 30.0) -> None:
     """Call before closing a socket that sent frames with ``release=True``: waits (bounded) until the peer has acknowledged everything, then frees
-    the slots; on timeout the pointers stay -- a slot that is never freed costs capacity, a slot freed too early costs correctness."""
+    the slots; on timeout the pointers stay -- a slot that is never freed costs capacity, a slot freed too early costs correctness.  The ledger
+    is dropped either way (`forget`): nothing of it may reach a later socket."""
     end = time.monotonic() + timeout
     while release_acked(sock):
         if time.monotonic() > end:
             break
         time.sleep(0.0005)
-    if not (_LEDGERS.get(sock.fileno()) or _SockLedger()).pending:
-        _LEDGERS.pop(sock.fileno(), None)
+    forget(sock)
 
 
 def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_left_on_socket: int, release: bool = False) -> int:
@@ -106,7 +141,7 @@ def send_chunk(sock, chunk_store: ChunkStore, chunk_req: ChunkRequest, n_chunks_
         sent = shm_arena.sendfile_payload(sock, frame_path)
         if sent != size:
             raise ConnectionError(f"chunk {chunk.chunk_id}: {sent} of {size} payload bytes sent")
-        led = _LEDGERS.setdefault(sock.fileno(), _SockLedger())
+        led = _ledger(sock, create=True)
         led.sent += len(header.to_bytes()) + size
         if release:
             led.pending.append((led.sent, frame_path))

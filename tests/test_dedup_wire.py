@@ -476,6 +476,12 @@ def test_segment_stores_are_bounded_and_distrust_epochs(tmp_path):
         with pytest.raises(dedup_wire.StoreEvicted):            # ... and a reference to what the budget took fails at once, it does not wait
             store.get(2, 0, fp(2))
         assert store.get(1, 0, fp(1)) == b"\x01" * 1000 and store.get(4, 0, fp(4)) is not None
+        # the mark is not sticky.  The silent lane resumes in the same epoch and sends its segments again: references to what has arrived
+        # SINCE the eviction resolve, only a reference to what is really gone fails
+        store.put_chunk(2, 0, [fp(22)], [0], [10], b"z" * 10)
+        assert store.get(2, 0, fp(22)) == b"z" * 10
+        with pytest.raises(dedup_wire.StoreEvicted):
+            store.get_many(2, 0, [fp(22), fp(2)])
         # a known lane that claims an epoch far ahead is refused (it would retire everything the lane holds); a small step is normal
         with pytest.raises(dedup_wire.RecipeError):
             store.put_chunk(1, 0xFFFFFFFF, [fp(9)], [0], [10], b"x" * 10)

@@ -189,6 +189,33 @@ def test_operator_zero_copy_staging_path(tmp_path, monkeypatch):
     op.worker_exit(0)
 
 
+def test_arena_slots_grow_when_a_larger_chunk_follows_a_small_first_batch(tmp_path, monkeypatch, capsys):
+    """slots sized by a first batch of small chunks must not disable the arena for the rest of the transfer."""
+    from skyplane_amd.gateway import shm_arena
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    store, q_in, q_out, reqs = _make_store(tmp_path, 2, size=70_001)
+    big = synth.gen_text(synth.rng_for(5), 300_000).tobytes()
+    cid = uuid.uuid4().hex
+    store.get_chunk_file_path(cid).write_bytes(big)
+    big_cr = ChunkRequest(chunk=Chunk(src_key="k", dest_key="k", chunk_id=cid, chunk_length_bytes=len(big), partition_id="0"))
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipCompress("gpu_compress_0", "local:test", q_in, q_out, err_ev, err_q, store, n_processes=1, max_batch=3, device_ids=[0],
+                            context_factory=_arena_factory, arena_slots=4)
+    op.worker_id = 0
+    crs = [cr for cr, _ in reqs]
+    assert op.process_batch(crs) == [True, True]
+    small = shm_arena.open_payload(store.get_compressed_file_path(crs[0].chunk.chunk_id))
+    assert small.arena is not None and small.arena.slot_bytes < len(big)
+    assert op.process_batch([big_cr]) == [True]
+    pl = shm_arena.open_payload(store.get_compressed_file_path(cid))
+    assert pl.arena is not None and pl.arena.slot_bytes >= len(big) and pl.arena.path != small.arena.path      # in a slot of the NEW arena, not a plain file
+    assert ref.lz4f_decompress(shm_arena.read_payload(store.get_compressed_file_path(cid)), len(big)) == big
+    assert ref.lz4f_decompress(shm_arena.read_payload(store.get_compressed_file_path(crs[0].chunk.chunk_id)), 70_001) == reqs[0][1]      # the old arena still serves its frames
+    assert "new arena with slots of" in capsys.readouterr().out
+    op.worker_exit(0)
+
+
 def test_operator_shared_arena_handoff(tmp_path, monkeypatch):
     """SURVEY 8f item 2, "pinned shared memory instead of tmpfs files": with handoff="arena" (the default) a frame is produced straight into a slot of
     one shared arena file in the chunk directory; `<id>.chunk.lz4f` is a pointer to the slot; the cooperating sender sendfile()s the slot and unlinks
@@ -234,9 +261,48 @@ def test_operator_shared_arena_handoff(tmp_path, monkeypatch):
     h = WireProtocolHeader.from_bytes(bytes(got[:53]))
     assert h.is_compressed and h.data_len == sent == len(got) - 53 and ref.lz4f_decompress(bytes(got[53:]), 70_001) == reqs[0][1]
     assert not store.get_compressed_file_path(crs[0].chunk.chunk_id).exists()
+    # a connection dies with a frame unacknowledged; the reconnect gets the SAME descriptor number and sends the frame again.  The new
+    # socket must start from an empty ledger (the old one was keyed by fileno and handed its byte count and pending list to the newcomer, which then
+    # freed the slot on the strength of bytes the dead connection had counted), and the slot goes back only when the LATER send is acknowledged.
+    ptr1 = store.get_compressed_file_path(crs[1].chunk.chunk_id)
+    c1, d1 = socket.socketpair()
+    fd_old = c1.fileno()
+    hip_sender.send_chunk(c1, store, crs[1], n_chunks_left_on_socket=0, release=True)
+    assert hip_sender.release_acked(c1) == 1 and ptr1.exists()
+    assert hip_sender.forget(c1) == 1 and ptr1.exists()                          # the error path: ledger dropped, nothing unlinked
+    c1.close(); d1.close()
+    c2, d2 = socket.socketpair()
+    if c2.fileno() != fd_old:                                                    # (make the descriptor number collide whatever the allocator did)
+        os.dup2(c2.fileno(), fd_old); c2.close(); c2 = socket.socket(fileno=fd_old)
+    assert hip_sender.release_acked(c2) == 0                                     # nothing inherited
+    hip_sender.send_chunk(c2, store, crs[1], n_chunks_left_on_socket=0, release=True)
+    assert hip_sender.release_acked(c2) == 1 and ptr1.exists()                   # the retry is in flight: the slot stays taken
+    got2 = bytearray()
+    rd2 = threading.Thread(target=lambda: [got2.extend(x) for x in iter(lambda: d2.recv(1 << 16), b"")])
+    rd2.start()
+    hip_sender.drain_releases(c2, timeout=10.0)
+    assert not ptr1.exists()
+    c2.close(); rd2.join(); d2.close()
+    assert ref.lz4f_decompress(bytes(got2[53:]), len(reqs[1][1])) == reqs[1][1]
+    # the same frame pending on two LIVE sockets (a retry while the first connection still drains): the first acknowledgement must not free the slot
+    ptr2 = store.get_compressed_file_path(crs[2].chunk.chunk_id)
+    e1, f1 = socket.socketpair(); e2, f2 = socket.socketpair()
+    hip_sender.send_chunk(e1, store, crs[2], n_chunks_left_on_socket=0, release=True)
+    hip_sender.send_chunk(e2, store, crs[2], n_chunks_left_on_socket=0, release=True)
+    sink = bytearray()
+    r1 = threading.Thread(target=lambda: [sink.extend(x) for x in iter(lambda: f1.recv(1 << 16), b"")]); r1.start()
+    t_end = time.monotonic() + 10.0
+    while hip_sender.release_acked(e1) and time.monotonic() < t_end:
+        time.sleep(0.001)
+    assert hip_sender.release_acked(e1) == 0 and ptr2.exists()                    # acknowledged on e1, still in flight on e2
+    r2 = threading.Thread(target=lambda: [sink.extend(x) for x in iter(lambda: f2.recv(1 << 16), b"")]); r2.start()
+    hip_sender.drain_releases(e2, timeout=10.0)
+    assert not ptr2.exists()
+    hip_sender.forget(e1)
+    e1.close(); e2.close(); r1.join(); r2.join(); f1.close(); f2.close()
     assert op.process_batch(crs[6:8]) == [True] * 2
     k2 = [shm_arena.open_payload(store.get_compressed_file_path(cr.chunk.chunk_id)).arena is not None for cr in crs[6:8]]
-    assert k2 == [True, False]                                                   # exactly the one freed slot was reused
+    assert k2 == [True, True]                                                    # the freed slots were reused
     # untrusted pointer files: wrong arena name, range outside the arena
     bad = tmp_path / "chunks" / "bad.chunk.lz4f"
     bad.write_bytes(shm_arena._PTR.pack(shm_arena.MAGIC, 4096, 10, 11) + b"../../passwd")
@@ -493,6 +559,30 @@ def test_bench_py_bare_gpus2_launches_itself():
     assert r["n_gpus"] == 2 and r["config"]["chunks_per_gpu"] == 8 and "2 resident half" in r["config"]["workload"]
     # every digest of the step, every frame still resident (the second half's) checked on every rank
     assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 8 and r["verified"]["frames_vs_liblz4"] == 4
+
+
+def test_bench_py_bare_gpus8_dry_run():
+    """The shape of the driver's 8-GPU scaling run, dry: `python bench.py --gpus 8` becomes eight ranks (gloo, the emulator as the device), every
+    rank holds its own share of the node's queue, every rank verifies, rank 0 alone prints ONE JSON line on stdout and the heartbeat goes to stderr."""
+    import json
+    import subprocess
+    import sys
+
+    from tests.emu import emulib
+    emulib.lib()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--context", "emu", "--chunk-bytes", "131072", "--chunks", "4", "--unit-mib", "1",
+           "--steps", "1", "--warmup", "0", "--max-batch", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["config"]["workload"].startswith("configs[3]: 8 MI355X") and r["config"]["chunks_per_gpu"] == 4
+    assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 4 and r["verified"]["frames_vs_liblz4"] == 4
+    assert abs(r["value"] - 8 * 4 * 131072 / (r["ms_per_step"] / 1e3) / 2**30) < 0.01 * r["value"] + 1e-3      # whole-job aggregate over the eight ranks
+    beats = [l for l in p.stderr.splitlines() if l.startswith("[bench +")]
+    assert any("timed region" in l for l in beats) and any("verifying" in l for l in beats) and "secondary" not in r
 
 
 def test_steady_state_e2e_script_with_emulated_device():
