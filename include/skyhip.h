@@ -166,6 +166,14 @@ int  skyhip_debug_prof(skyhip_ctx* ctx, uint64_t out[16]);
    must leave the context usable */
 int  skyhip_debug_fault(skyhip_ctx* ctx, long n);
 
+/* test instrumentation (tests/test_gpu_guard.py): device buffers placed with the HIP virtual-memory API so that they END on the last mapped byte before an
+   unmapped address range (at_end != 0) or START right behind one -- a kernel that touches one byte outside dies with a memory access fault.  With
+   SKYHIP_GUARD_ALLOC=1 in the environment the library places every device buffer it allocates for itself the same way, with no slack.  _probe reads one
+   byte at p on the device and returns it. */
+int  skyhip_debug_guard_alloc(size_t bytes, int at_end, void** out);
+int  skyhip_debug_guard_free(void* p);
+int  skyhip_debug_guard_probe(skyhip_ctx* ctx, const void* p);
+
 const char* skyhip_strerror(int code);
 const char* skyhip_last_hip_error(skyhip_ctx* ctx);   /* hipGetErrorString of the last failing HIP call; ctx == NULL: of this thread's last failed skyhip_create */
 

@@ -14,6 +14,7 @@ EXPORTS = (
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
     "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault", "skyhip_host_register", "skyhip_host_unregister",
+    "skyhip_debug_guard_alloc", "skyhip_debug_guard_free", "skyhip_debug_guard_probe",
 )
 
 
@@ -81,6 +82,12 @@ def load() -> C.CDLL:
     lib.skyhip_reset_timing.restype = None
     lib.skyhip_debug_fault.argtypes = [vp, C.c_long]
     lib.skyhip_debug_fault.restype = C.c_int
+    lib.skyhip_debug_guard_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.skyhip_debug_guard_alloc.restype = C.c_int
+    lib.skyhip_debug_guard_free.argtypes = [vp]
+    lib.skyhip_debug_guard_free.restype = C.c_int
+    lib.skyhip_debug_guard_probe.argtypes = [vp, vp]
+    lib.skyhip_debug_guard_probe.restype = C.c_int
     lib.skyhip_selftest.argtypes = [vp]
     lib.skyhip_selftest.restype = C.c_int
     lib.skyhip_decompress_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -138,6 +138,10 @@ extern "C" __global__ void __launch_bounds__(64) sky_selftest_kernel(const uint8
     }
 }
 
+extern "C" __global__ void __launch_bounds__(64) sky_probe_kernel(const uint8_t* p, uint32_t* out) {
+    if (sky_lane() == 0) *out = *(const volatile uint8_t*)p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -146,9 +150,78 @@ namespace {
 struct EvPair { hipEvent_t a, b; int kind; };
 enum { K_LZ4 = 0, K_LAYOUT, K_GATHER, K_MD5, K_CDC, K_N };
 
+// ---- guard-band device allocations (test instrumentation: tests/test_gpu_guard.py) ----------------------------------------------------------------
+// The device twin of the emulator's PROT_NONE fences (tests/test_emu_guard.py): a buffer is placed with the HIP virtual-memory API so that it ENDS on the
+// last mapped byte before an unmapped address range (or starts right behind one); a kernel that reads or writes one byte too far then dies with a memory
+// access fault instead of quietly reading its neighbour -- which is what a hipMalloc'ed buffer lets it do.  With SKYHIP_GUARD_ALLOC=1 in the environment
+// every device buffer the library allocates for itself (staging areas, block scratch, metadata, decoder tables) is placed that way, with NO slack behind
+// what was asked for; skyhip_debug_guard_alloc hands the same kind of buffer to a test for the caller-owned side (d_in / d_out).  Never set in production:
+// every ensure() that changes a size re-maps.
+struct SkyGuardBlock { void* user; void* va; size_t va_size; void* map_at; size_t map_size; hipMemGenericAllocationHandle_t h; };
+static std::mutex g_guard_mu;
+static std::vector<SkyGuardBlock> g_guard_blocks;
+static bool sky_guard_on() {
+    static const bool on = [] { const char* e = getenv("SKYHIP_GUARD_ALLOC"); return e && atoi(e) > 0; }();
+    return on;
+}
+// at_end: the buffer's last byte is the last mapped byte (its start is then only as aligned as `bytes` is, rounded down to `align`: up to align - 1 bytes of
+// slack behind a buffer whose size is not a multiple of it); otherwise its first byte is the first mapped byte
+static hipError_t sky_guard_malloc(void** out, size_t bytes, bool at_end, size_t align) {
+    *out = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    if (gran < 4096) gran = 4096;
+    SkyGuardBlock b = {};
+    b.map_size = ((bytes ? bytes : 1) + gran - 1) / gran * gran;
+    b.va_size = b.map_size + 2 * gran;
+    if ((e = hipMemAddressReserve(&b.va, b.va_size, gran, nullptr, 0)) != hipSuccess) return e;
+    b.map_at = (char*)b.va + gran;
+    if ((e = hipMemCreate(&b.h, b.map_size, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(b.va, b.va_size); return e; }
+    if ((e = hipMemMap(b.map_at, b.map_size, 0, b.h, 0)) != hipSuccess) { (void)hipMemRelease(b.h); (void)hipMemAddressFree(b.va, b.va_size); return e; }
+    hipMemAccessDesc ad = {};
+    ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(b.map_at, b.map_size, &ad, 1)) != hipSuccess) {
+        (void)hipMemUnmap(b.map_at, b.map_size); (void)hipMemRelease(b.h); (void)hipMemAddressFree(b.va, b.va_size); return e;
+    }
+    b.user = at_end ? (void*)(((uintptr_t)b.map_at + b.map_size - bytes) & ~(uintptr_t)(align ? align - 1 : 0)) : b.map_at;
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard_blocks.push_back(b);
+    *out = b.user;
+    return hipSuccess;
+}
+static hipError_t sky_guard_free(void* p) {
+    SkyGuardBlock b = {};
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        size_t i = 0;
+        for (; i < g_guard_blocks.size(); i++) if (g_guard_blocks[i].user == p) break;
+        if (i == g_guard_blocks.size()) return hipErrorInvalidValue;
+        b = g_guard_blocks[i];
+        g_guard_blocks.erase(g_guard_blocks.begin() + (long)i);
+    }
+    (void)hipDeviceSynchronize();
+    hipError_t e = hipMemUnmap(b.map_at, b.map_size);
+    (void)hipMemRelease(b.h);
+    (void)hipMemAddressFree(b.va, b.va_size);
+    return e;
+}
+
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t n) {
+        if (sky_guard_on()) {      // exactly n elements, the last one against an unmapped page; a new size = a new mapping
+            if (n == cap && p) return hipSuccess;
+            if (p) (void)sky_guard_free(p);
+            p = nullptr; cap = 0;
+            hipError_t e = sky_guard_malloc((void**)&p, n * sizeof(T), true, 16);
+            if (e == hipSuccess) cap = n;
+            return e;
+        }
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
@@ -157,7 +230,7 @@ template <typename T> struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { if (sky_guard_on()) (void)sky_guard_free(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 template <typename T> struct PinBuf {
     T* p = nullptr; size_t cap = 0;
@@ -908,6 +981,26 @@ int skyhip_debug_fault(skyhip_ctx* c, long n) {
     if (!c) return SKYHIP_E_INVAL;
     c->fault_after = n;
     return SKYHIP_OK;
+}
+
+// guard-band buffers for the caller-owned side of the device-resident calls (tests/test_gpu_guard.py); a device must be current (after skyhip_create)
+int skyhip_debug_guard_alloc(size_t bytes, int at_end, void** out) {
+    if (!out) return SKYHIP_E_INVAL;
+    const hipError_t e = sky_guard_malloc(out, bytes, at_end != 0, 1);
+    return e == hipSuccess ? SKYHIP_OK : (e == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP);
+}
+int skyhip_debug_guard_free(void* p) { return sky_guard_free(p) == hipSuccess ? SKYHIP_OK : SKYHIP_E_INVAL; }
+// reads ONE byte at p on the device and returns it (>= 0): the harness's own proof that a byte past a guarded buffer kills the process
+int skyhip_debug_guard_probe(skyhip_ctx* c, const void* p) {
+    if (!c || !p) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (!c->d_self) HIPCHK(c, hipMalloc((void**)&c->d_self, 64));
+    hipLaunchKernelGGL(sky_probe_kernel, dim3(1), dim3(64), 0, c->s_lz4, (const uint8_t*)p, c->d_self);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    uint32_t v = 0;
+    HIPCHK(c, hipMemcpy(&v, c->d_self, 4, hipMemcpyDeviceToHost));
+    return (int)(v & 0xFFu);
 }
 
 int skyhip_selftest(skyhip_ctx* c) {
