@@ -174,7 +174,7 @@ static hipError_t sky_guard_malloc(void** out, size_t bytes, bool at_end, size_t
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
     size_t gran = 0;
-    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended)) != hipSuccess) return e;
     if (gran < 4096) gran = 4096;
     SkyGuardBlock b = {};
     b.map_size = ((bytes ? bytes : 1) + gran - 1) / gran * gran;
@@ -207,7 +207,9 @@ static hipError_t sky_guard_free(void* p) {
     (void)hipDeviceSynchronize();
     hipError_t e = hipMemUnmap(b.map_at, b.map_size);
     (void)hipMemRelease(b.h);
-    (void)hipMemAddressFree(b.va, b.va_size);
+    // The address range is NOT given back: the next reservation would get the same addresses, and buffers that were unmapped and mapped again at one
+    // address within milliseconds read and wrote each other's bytes (GPU call r5c: wrong frames and digests at a different case in every run, no fault) --
+    // a translation that outlives its mapping.  A test process reserves a few hundred ranges of a 47-bit space; nothing is lost.
     return e;
 }
 

@@ -33,7 +33,14 @@ def hip():
         _hip.hipMemcpy.restype = C.c_int
         _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         _hip.hipMemset.restype = C.c_int
+        _hip.hipDeviceSynchronize.restype = C.c_int
     return _hip
+
+
+def dsync():
+    """hipMemset (and a pageable hipMemcpy's last leg) may still be running when the call returns, and the library's streams are non-blocking: they do not
+    wait for the null stream.  Everything this harness puts on the device is complete before the library sees it."""
+    assert hip().hipDeviceSynchronize() == 0
 
 
 class Guarded:
@@ -48,11 +55,13 @@ class Guarded:
         self.user = self.ptr + (max(self.n, 1) - self.n if at_end else 0)      # (a zero-byte buffer: one byte was mapped, the buffer is the empty range at its end)
         if fill is not None:
             assert hip().hipMemset(self.ptr, fill, max(self.n, 1)) == 0
+            dsync()
 
     def upload(self, data, at: int = 0):
         b = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
         if b.size:
             assert hip().hipMemcpy(self.user + at, b.ctypes.data, b.size, 1) == 0
+            dsync()
 
     def download(self, at: int, n: int) -> bytes:
         out = np.empty(n, np.uint8)
@@ -125,6 +134,7 @@ def run_lz4():
                 if n >= gc.BLK - 1 and name in ("period3",):
                     continue
                 for at_end in (True, False):
+                    print(f"lz4 n={n} {name} at_end={at_end}", flush=True)
                     _device_case(lib, ctx, [data], at_end=at_end)
                     n_cases += 1
         _device_case(lib, ctx, [bytes(70000), b"x" * 13, b"", bytes(gc.BLK)])
@@ -139,6 +149,7 @@ def run_batch():
             for name, data in gc.patterns(n, n + 7):
                 if n >= gc.BLK - 1 and name in ("period3",):
                     continue
+                print(f"batch n={n} {name}", flush=True)
                 (r,) = ctx.process_batch([data])
                 assert r.md5 == hashlib.md5(data).digest() and ref.lz4f_decompress(r.frame, n) == data, (n, name)
                 outs, digs = ctx.decompress_batch([ref.lz4f_compress(data)], [n], want_md5=True)
@@ -171,6 +182,7 @@ def run_lz4d():
         for r, d in zip(ctx.process_batch([c[2] for c in cases[:40:3]]), [c[2] for c in cases[:40:3]]):      # and our own frames of some of them
             cases.append((f"ours {len(d)}", r.frame, d))
         for label, frame, data in cases:
+            print(f"lz4d {label}", flush=True)
             gin = Guarded(lib, len(frame), at_end=True)
             gout = Guarded(lib, len(data), at_end=True, fill=0xEE)
             gin.upload(frame)
@@ -194,6 +206,7 @@ def run_cdc():
                     continue
                 want = [int(x) for x in ref.gear_cdc(data)]
                 for at_end in (True, False):
+                    print(f"cdc n={n} {name} at_end={at_end}", flush=True)
                     gin = Guarded(lib, n, at_end=at_end)
                     gin.upload(data)
                     ctx.dedup_reset()

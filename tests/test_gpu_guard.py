@@ -16,7 +16,12 @@ pytestmark = pytest.mark.gpu
 
 def _run(case, timeout=600, **env):
     e = dict(os.environ, SKYHIP_GUARD_ALLOC="1", AMD_SERIALIZE_KERNEL="3", HSA_ENABLE_IPC_MODE_LEGACY="0", **{k: str(v) for k, v in env.items()})
-    return subprocess.run([sys.executable, str(ROOT / "tests" / "_gpu_guard_run.py"), case], capture_output=True, text=True, timeout=timeout, env=e, cwd=str(ROOT))
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "_gpu_guard_run.py"), case], capture_output=True, text=True, timeout=timeout, env=e, cwd=str(ROOT))
+    if os.environ.get("GUARD_LOG_DIR"):      # (a development aid: the whole transcript of every child, e.g. under gpurun_out/)
+        tag = case + "".join(f"_{k}{v}" for k, v in env.items())
+        Path(os.environ["GUARD_LOG_DIR"]).mkdir(parents=True, exist_ok=True)
+        (Path(os.environ["GUARD_LOG_DIR"]) / f"guard_{tag}.log").write_text(f"rc={p.returncode}\n--- stdout\n{p.stdout}\n--- stderr\n{p.stderr}")
+    return p
 
 
 def test_the_fence_works_one_byte_past_and_one_byte_before():
@@ -35,7 +40,7 @@ def test_the_fence_works_one_byte_past_and_one_byte_before():
 def test_kernels_stay_inside_their_buffers_on_the_gpu(case, env):
     p = _run(case, **env)
     assert p.returncode == 0 and f"OK {case}" in p.stdout, \
-        f"rc={p.returncode} (a memory access fault = a kernel touched memory outside its buffer)\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+        f"rc={p.returncode} (a memory access fault = a kernel touched memory outside its buffer; the last line names the case)\n{p.stdout[-600:]}\n{p.stderr[-3000:]}"
 
 
 def test_frames_in_place_at_production_shape_inside_the_fences():
