@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=1024, help="chunks per LZ4 launch on the block-queue path (device-resident batches below 2 chunks per CU and "
                                                                 "SKYHIP_FRAMES_MIN=0 runs; block scratch = 8.06 MiB per chunk); the default run writes frames in place and never uses it")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] / configs[3]-on-one-GPU runs appended to the default 1-GPU line")
-    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--secondary-steps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", choices=["auto", "silesia", "mixed"], default="auto",
                     help="auto = silesia (configs[1]) on one GPU, mixed (configs[3]) on several")
@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--verify", choices=["full", "sample", "none"], default="full", help="post-run check of digests (all / 64 chunks) and of sampled frames")
     ap.add_argument("--context", choices=["hip", "emu"], default="hip", help="emu = CPU emulator + gloo (tests of this file's rank logic only)")
     ap.add_argument("--chunk-bytes", type=int, default=synth.CHUNK_BYTES, help="tests only; the metric is defined on 8 MiB chunks")
+    ap.add_argument("--md5-lanes", type=int, default=0, help="experiment: digest chains as their own device calls on this many extra contexts (0 = inside the "
+                    "compressor's call, the default): see the comment at md5_lanes below")
     ap.add_argument("--depth", type=int, default=0, help="steps in flight (0 = 2 when a second set of frame slots fits beside the stream, else 1): "
                     "step k + 1's compressor runs while step k's digest chains finish, the way the gateway operator's lanes overlap their batches")
     ap.add_argument("--halves", type=int, default=0, help="tests only: resident halves per step (0 = 2 when the stream has more than 8192 chunks)")
@@ -279,6 +281,12 @@ def main():
     pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None
 
     log(f"host unit of {unit_bytes >> 20} MiB generated, CPU pool of {pool_n} forked")
+    if args.cdc:
+        # configs[2] keeps four kernel streams of two contexts busy at once (compressor, whole-chunk digests, CDC chain, x 2 steps in flight).  The HIP runtime
+        # maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin, and kernels of streams that share a queue run one after
+        # the other: with 12 streams on 4 queues a step's CDC chain sat behind the OTHER step's 150 ms digest launch (GPU calls r5g-r5m: 352-412 GiB/s at 4
+        # queues, 410-423 at 16 with the library's filler-sized CDC grids).  Read by the runtime when it initialises, i.e. at `import torch` below.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch  # noqa: E402  (imported before libskyhip so both share one HIP runtime; no device touched before the fork above)
 
     if emu:
@@ -373,21 +381,36 @@ def main():
         ctxs = [hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch) for _ in range(depth)]
         p_in, p_outs = d_in.data_ptr(), [t.data_ptr() for t in d_outs]
     ctx = ctxs[0]
-    flags = hip_ops.F_LZ4 | hip_ops.F_MD5 | ((hip_ops.F_CDC | hip_ops.F_DEDUP) if args.cdc else 0)
+    # Digest lanes (--md5-lanes M, an experiment switch; default 0 = the digests ride in the compressor's call): a step's digest chains as their OWN device
+    # call (flags = MD5 only, own context and streams).  A chain needs no frame slots, so more steps' chains could be in flight than calls that compress.
+    # Measured (GPU calls r5g-r5j): no gain -- 386 against 551 GiB/s on configs[1] at the default 4 hardware queues (more streams, more queue sharing), equal
+    # at 16; configs[2] 308-397 against 385-423.  The chip's time per step is the SUM of what compressor, candidates and segment digests need alone (they
+    # compete for the same LDS and issue slots), not the longest of them: deeper pipelining of the one latency-bound kernel buys nothing.
+    md5_lanes = args.md5_lanes if args.md5_lanes > 0 else 0
+    if emu:
+        md5_lanes = 0
+    flags = hip_ops.F_LZ4 | (hip_ops.F_MD5 if md5_lanes == 0 else 0) | ((hip_ops.F_CDC | hip_ops.F_DEDUP) if args.cdc else 0)
     lasts = [{} for _ in range(depth)]
+    md5_ctxs = [hip_ops.SkyHipContext(device_id=local_rank, max_chunk_bytes=cb, max_batch=args.max_batch) for _ in range(md5_lanes)]
+    md5_lasts = [{} for _ in range(md5_lanes)]
 
     def step(lane=0):
         if args.cdc:
             ctxs[lane].dedup_reset()      # every step sees the stream for the first time
         # ONE call for the whole resident stream: one MD5 launch over every chunk (a chain per chunk, all chains at once) beside the compressor
         # (out_off_all: a slot per chunk, or -- share_slots, when HBM is short -- the second half's frames over the first half's)
-        lasts[lane]["out_len"], lasts[lane]["md5"] = ctxs[lane].process_device(p_in, in_off, in_len, p_outs[lane], out_off_all, out_cap_all, flags)
+        lasts[lane]["out_len"], md5_ = ctxs[lane].process_device(p_in, in_off, in_len, p_outs[lane], out_off_all, out_cap_all, flags)
+        if md5_lanes == 0:
+            lasts[lane]["md5"] = md5_
+
+    def md5_step(m):
+        _ol, md5_lasts[m]["md5"] = md5_ctxs[m].process_device(p_in, in_off, in_len, 0, in_off, in_off, hip_ops.F_MD5)
 
     def run_steps(k_steps):
         """k_steps steps, `depth` of them in flight: lane j (its own context, streams and frame slots) runs steps j, j + depth, ...  A step's digest
         chains (one per chunk, ~82 ms when alone, longer beside the compressor) end after its compressor launch does; with a second step in flight the
         next compressor launch runs meanwhile instead of waiting for them."""
-        if depth == 1:
+        if depth == 1 and md5_lanes == 0:
             for _ in range(k_steps):
                 step(0)
             return
@@ -402,7 +425,14 @@ def main():
             except BaseException as e:      # noqa: BLE001
                 errs.append(e)
 
-        ths = [threading.Thread(target=lane_loop, args=(j,)) for j in range(depth)]
+        def md5_loop(m):
+            try:
+                for _ in range(m, k_steps, md5_lanes):
+                    md5_step(m)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=lane_loop, args=(j,)) for j in range(depth)] + [threading.Thread(target=md5_loop, args=(m,)) for m in range(md5_lanes)]
         for t in ths:
             t.start()
         for t in ths:
@@ -416,13 +446,13 @@ def main():
 
     log(f"stream resident ({n_chunks} chunks of {cb} B per rank, {halves} half(s), depth {depth}, setup {gen_s:.1f}s); warmup")
     run_steps(args.warmup)
-    if depth > 1 and args.warmup < depth:
-        run_steps(depth - args.warmup)      # every lane's context has run once before the clock starts
-    for c_ in ctxs:
+    if max(depth, md5_lanes) > 1 and args.warmup < max(depth, md5_lanes):
+        run_steps(max(depth, md5_lanes) - args.warmup)      # every lane's context has run once before the clock starts
+    for c_ in ctxs + md5_ctxs:
         c_.reset_timing()
     log(f"timed region: {args.steps} steps")
     _local, elapsed = shard.timed_region(lambda: run_steps(args.steps), 1, dist=dist, sync=sync)      # EXACTLY args.steps steps between barrier + synchronize, MAX over ranks
-    tms = [c_.timing() for c_ in ctxs]
+    tms = [c_.timing() for c_ in ctxs + md5_ctxs]
 
     class _Tm:
         pass
@@ -431,11 +461,15 @@ def main():
     for f in ("lz4_ms", "layout_ms", "gather_ms", "md5_ms", "cdc_ms", "lz4_launches", "lz4_in_bytes", "lz4_out_bytes", "md5_launches", "md5_in_bytes"):
         setattr(tm, f, sum(getattr(t, f) for t in tms))
     last_lane = (args.steps - 1) % depth if args.steps >= depth else 0
-    out_len, md5 = lasts[last_lane]["out_len"], lasts[last_lane]["md5"]
+    out_len = lasts[last_lane]["out_len"]
+    md5 = lasts[last_lane]["md5"] if md5_lanes == 0 else md5_lasts[(args.steps - 1) % md5_lanes if args.steps >= md5_lanes else 0]["md5"]
     d_out = d_outs[last_lane]
     for j in range(depth):      # every lane hashed and compressed the same stream: same digests, same frame lengths
         if lasts[j]:
-            assert np.array_equal(lasts[j]["md5"], md5) and np.array_equal(lasts[j]["out_len"], out_len), f"lane {j} disagrees with lane {last_lane}"
+            assert (md5_lanes or np.array_equal(lasts[j]["md5"], md5)) and np.array_equal(lasts[j]["out_len"], out_len), f"lane {j} disagrees with lane {last_lane}"
+    for m in range(md5_lanes):
+        if md5_lasts[m]:
+            assert np.array_equal(md5_lasts[m]["md5"], md5), f"digest lane {m} disagrees"
     # the second roofline (min(HBM, chain)): MD5 is one serial chain per chunk, so a step can never be shorter than one chain however
     # many lanes idle.  Measured, outside the timed region: the digest kernel alone over the same resident chunks.
     md5_alone_ms = None
@@ -520,7 +554,7 @@ def main():
                                    f"{n_chunks * cb / 2**30:.0f} GiB/GPU = {n_chunks} chunks per step in {halves} resident half(s){' sharing frame slots' if share_slots and halves > 1 else ''}, {unit_bytes >> 20} MiB unit tiled + rotated",
                        "chunk_bytes": cb, "chunks_per_gpu": n_chunks, "lz4_ratio": round(n_chunks * cb / comp_bytes, 4),
                        "sharding": "chunk i of the node's queue on rank i % N, no collective on the data path" if world > 1 else "single GPU", "max_batch": args.max_batch,
-                       "steps_in_flight": depth, "lz4_path": "frames written in place, one launch per step" if in_place else "block queue + frame gather, sub-batches of max_batch"},
+                       "steps_in_flight": depth, "digest_lanes": md5_lanes, "lz4_path": "frames written in place, one launch per step" if in_place else "block queue + frame gather, sub-batches of max_batch"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "avg_launch_ms": round(tm.lz4_ms / max(tm.lz4_launches, 1), 4), "launches": int(tm.lz4_launches),
@@ -581,7 +615,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(pool, cores, quota, rots, 12.0 if world == 1 else 6.0)
     if pool is not None:
         pool.close(); pool.join()
-    for c_ in ctxs:
+    for c_ in ctxs + md5_ctxs:
         c_.close()
     if rank == 0:
         default_run = world == 1 and not emu and not args.cdc and args.stream == "auto" and args.chunks == 0 and cb == synth.CHUNK_BYTES

@@ -8,6 +8,8 @@ $R/scripts/pmc.sh $OUT silesia "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum" -- 
 python $R/scripts/pmc_traffic.py $OUT silesia 8192 sky_lz4s_frames
 $R/scripts/pmc.sh $OUT mixed "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum" -- python $R/bench.py $B --stream mixed --chunks 16384
 python $R/scripts/pmc_traffic.py $OUT mixed 16384 sky_lz4s_frames
+$R/scripts/pmc.sh $OUT cdc "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum" -- python $R/bench.py $B --cdc
+python $R/scripts/pmc_traffic.py $OUT cdc 8192 sky_lz4s_frames
 # the calibration: the same kernel built without the prefetch touches must show one request per line and FETCH_SIZE = half of the input
 if [ -f $R/scripts/dev/libskyhip_nopf.so ]; then
   SKYHIP_LIB_PATH=$R/scripts/dev/libskyhip_nopf.so $R/scripts/pmc.sh $OUT nopf "FETCH_SIZE" "TCC_EA0_RDREQ_sum" -- env CHUNKS=1024 ONLY=lz4 python $R/scripts/dev/lz4s_exp.py

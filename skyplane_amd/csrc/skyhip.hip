@@ -85,16 +85,18 @@ extern "C" __global__ void __launch_bounds__(64) sky_lz4_decode_seq(SkyLz4dRun r
     sky_lz4_decode_seq_body(r, smem);
 }
 #ifdef SKY_WITH_CDC
-extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) sky_gear_candidates(SkyGearArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    sky_gear_candidates_body(a, smem);
+#define SKY_GEAR_LDS_ORIGIN 16u      // the kernel's only LDS, addressed absolutely like the compressor's: no `v_add_u32 v, <link-time base>, v` per table look-up
+extern "C" __global__ void __launch_bounds__(SKY_GEAR_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) sky_gear_candidates(SkyGearArgs a) {      // <= 64 VGPRs
+    typedef __attribute__((address_space(3))) uint8_t sky_lds_u8;
+    sky_gear_candidates_body(a, (uint8_t*)(sky_lds_u8*)(uintptr_t)SKY_GEAR_LDS_ORIGIN);
 }
 extern "C" __global__ void __launch_bounds__(64) sky_gear_select(SkyGearArgs a) { sky_gear_select_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_seg_prefix(SkySegPrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_seg_prefix_body(a, smem);
 }
-extern "C" __global__ void __launch_bounds__(64) sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_seg_desc(SkySegDescArgs a) { sky_seg_desc_body(a); }
+extern "C" __global__ void __launch_bounds__(64) SKY_MD5_KERNEL_ATTR sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }      // <= 128 VGPRs like sky_md5_chunks: runs beside the compressor
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_insert(SkyDedupArgs a) { sky_dedup_insert_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_resolve(SkyDedupArgs a) { sky_dedup_resolve_body(a); }
 #endif
@@ -430,7 +432,11 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         HIPCHK(c, c->d_queue.ensure(16));
         { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) { c->md5_wg = v; c->md5_wg_env = true; } }
 #ifdef SKY_WITH_CDC
-        HIPCHK(c, hipFuncSetAttribute((const void*)sky_gear_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_GEAR_LDS_BYTES));
+        c->cdc.segmd5_grid = (uint32_t)c->lz4s_grid * 32u;
+        c->cdc.gear_grid_beside = (uint32_t)c->lz4s_grid * 4u; c->cdc.segmd5_grid_beside = (uint32_t)c->lz4s_grid * 8u;
+        if (const char* e = getenv("SKYHIP_GEAR_BESIDE")) { const int v = atoi(e); if (v > 0) c->cdc.gear_grid_beside = (uint32_t)c->lz4s_grid * (uint32_t)v; }        // (tuning: wavefronts per CU)
+        if (const char* e = getenv("SKYHIP_SEGMD5_BESIDE")) { const int v = atoi(e); if (v > 0) c->cdc.segmd5_grid_beside = (uint32_t)c->lz4s_grid * (uint32_t)v; }
+        c->cdc.gear_grid = (uint32_t)c->lz4s_grid * 32u;      // wavefronts of sky_gear_candidates: what the chip holds when the kernel has it to itself
 #endif
         if (getenv("SKYHIP_DEBUG")) {
             int nbs = 0;
@@ -575,7 +581,8 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         HIPCHK(c, hipMemcpyAsync(c->h_md5.p, c->d_md5.p, 16 * N, hipMemcpyDeviceToHost, c->s_md5));
         c->tm.md5_launches++; c->tm.md5_in_bytes += bytes_total;
     }
-    // ---- CDC (+ fingerprints, dedup) on its own stream ----
+    const bool frames_in_place = (flags & SKYHIP_F_LZ4) && !pipe && c->frames_min > 0 && N >= (size_t)c->frames_min;
+    // ---- CDC (+ fingerprints, dedup) on its own stream, beside the compressor (cdc_host.inc: the grids are sized for that) ----
     if (flags & SKYHIP_F_CDC) {
 #ifndef SKY_WITH_CDC
         return SKYHIP_E_INVAL;
@@ -585,14 +592,13 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         EvPair ep;
         if ((rc = ev_begin(c, c->s_cdc, K_CDC, &ep))) return rc;
         rc = sky_cdc_run(&c->cdc, c->s_cdc, (const uint8_t*)d_in, c->d_in_off.p, c->d_in_len.p, c->h_in_len.p, (uint32_t)N,
-                         (flags & SKYHIP_F_DEDUP) != 0, c->hip_err, sizeof c->hip_err);
+                         (flags & SKYHIP_F_DEDUP) != 0, c->hip_err, sizeof c->hip_err, frames_in_place);
         if (rc) return rc;
         if ((rc = ev_end(c, c->s_cdc, ep))) return rc;
 #endif
     }
     // ---- LZ4: sub-batches of max_batch chunks; the compressor (s_lz4) writes block scratch k & 1 while the frames of sub-batch k-1 are laid out
     //      and gathered out of the other buffer on s_fr ----
-    const bool frames_in_place = (flags & SKYHIP_F_LZ4) && !pipe && c->frames_min > 0 && N >= (size_t)c->frames_min;
     if (frames_in_place) {
         // ---- LZ4, large device-resident batch: ONE launch, a workgroup per chunk at a time, every frame written in place (no scratch, no gather) ----
         SkyLz4FArgs fa;

@@ -139,6 +139,17 @@ SKY_DEV uint32_t sky_push(uint32_t to, uint32_t v) { return (uint32_t)__builtin_
 // (a 32-bit v_mul_lo_u32 issues at a quarter of that rate)
 SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+// byte k (0..3, compile-time) of w, times 8 -- the byte offset of entry [byte] in a table of 8-byte entries -- in ONE instruction: the shift reads its
+// operand through SDWA's byte select (the compiler emits v_bfe_u32 + v_lshl_add_u32 for the same thing)
+SKY_DEV uint32_t sky_byte_x8(uint32_t w, int k) {
+    uint32_t r;
+    const uint32_t three = 3u;
+    if (k == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+    else if (k == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+    else if (k == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+}
 // v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {hi, lo} (0-3 = lo's bytes, 4-7 = hi's, 0x0c = 0x00)
 SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // bits = 2 * bits + (a < b)  /  + (a == b): a compare into VCC and v_addc_co_u32 bits, bits, bits, vcc -- two VALU instructions per position and no

@@ -82,6 +82,7 @@ SKY_DEV int sky_ctz64(sky_u64 x) { return __builtin_ctzll(x); }
 SKY_DEV int sky_popc64(sky_u64 x) { return __builtin_popcountll(x); }
 SKY_DEV uint32_t sky_mul24(uint32_t a, uint32_t b) { return (uint32_t)((sky_u64)(a & 0xFFFFFFu) * (sky_u64)(b & 0xFFFFFFu)); }
 SKY_DEV uint32_t sky_mad24(uint32_t a, uint32_t b, uint32_t c) { return sky_mul24(a, b) + c; }
+SKY_DEV uint32_t sky_byte_x8(uint32_t w, int k) { return ((w >> (8 * k)) & 0xFFu) << 3; }
 SKY_DEV uint32_t sky_perm(uint32_t hi, uint32_t lo, uint32_t sel) {      // v_perm_b32 (selectors 0-7 and 0x0c only: what the kernels use)
     const sky_u64 both = ((sky_u64)hi << 32) | lo;
     uint32_t r = 0;

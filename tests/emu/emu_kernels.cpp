@@ -151,6 +151,7 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
 static void k_gcand(void* a, uint8_t* smem) { sky_gear_candidates_body(*(SkyGearArgs*)a, smem); }
 static void k_gsel(void* a, uint8_t*) { sky_gear_select_body(*(SkyGearArgs*)a); }
 static void k_segpre(void* a, uint8_t* smem) { sky_seg_prefix_body(*(SkySegPrefixArgs*)a, smem); }
+static void k_segdesc(void* a, uint8_t*) { sky_seg_desc_body(*(SkySegDescArgs*)a); }
 static void k_segmd5(void* a, uint8_t*) { sky_segment_md5_body(*(SkySegMd5Args*)a); }
 static void k_dins(void* a, uint8_t*) { sky_dedup_insert_body(*(SkyDedupArgs*)a); }
 static void k_dres(void* a, uint8_t*) { sky_dedup_resolve_body(*(SkyDedupArgs*)a); }
@@ -173,16 +174,21 @@ long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, 
     std::vector<sky_u64> fs(slots);
     SkyGearArgs ga; ga.in = in; ga.in_off = off.data(); ga.in_len = len.data(); ga.tile_prefix = tile_prefix.data(); ga.n_chunks = (uint32_t)n; ga.n_tiles = tiles;
     ga.gear = (const sky_u64*)gear; ga.cand = cand.data(); ga.cand_cnt = cand_cnt.data(); ga.cut_prefix = cut_prefix.data(); ga.cuts = cuts.data(); ga.n_cuts = ncuts.data();
-    if (tiles) emu_launch(tiles, SKY_GEAR_THREADS, SKY_GEAR_LDS_BYTES, k_gcand, &ga);
+    uint32_t tile_queue = 0;
+    ga.queue = &tile_queue;
+    if (tiles) emu_launch(tiles < 3u ? (int)tiles : 3, SKY_GEAR_THREADS, SKY_GEAR_LDS_BYTES, k_gcand, &ga);      // a persistent grid smaller than the tile count
     if (cand_cnt_out) for (uint32_t t = 0; t < tiles; t++) cand_cnt_out[t] = cand_cnt[t];
     emu_launch(n, 64, 0, k_gsel, &ga);
     SkySegPrefixArgs pa; pa.n_cuts = ncuts.data(); pa.seg_prefix = seg_prefix.data(); pa.n_chunks = (uint32_t)n;
     emu_launch(1, 256, 64, k_segpre, &pa);
     const uint32_t total = seg_prefix[n];
     if (total > seg_cap) return -5;
-    SkySegMd5Args ma; ma.in = in; ma.in_off = off.data(); ma.cut_prefix = cut_prefix.data(); ma.cuts = cuts.data(); ma.seg_prefix = seg_prefix.data();
-    ma.n_chunks = (uint32_t)n; ma.max_segs = slots; ma.fps = fps.data(); ma.seg_end = seg_end.data();
-    emu_launch((slots + 63) / 64, 64, 0, k_segmd5, &ma);
+    std::vector<sky_u64> desc(slots ? slots : 1);
+    SkySegDescArgs sa; sa.in_off = off.data(); sa.cut_prefix = cut_prefix.data(); sa.cuts = cuts.data(); sa.n_cuts = ncuts.data(); sa.seg_prefix = seg_prefix.data();
+    sa.n_chunks = (uint32_t)n; sa.desc = desc.data(); sa.seg_end = seg_end.data();
+    emu_launch((n + 3) / 4, 256, 0, k_segdesc, &sa);
+    SkySegMd5Args ma; ma.in = in; ma.desc = desc.data(); ma.seg_total = &seg_prefix[n]; ma.max_segs = slots; ma.fps = fps.data();
+    emu_launch(total > 200u ? 2 : 1, 64, 0, k_segmd5, &ma);      // a persistent grid: every lane walks several segments (two wavefronts when there are enough)
     if (dedup) {
         SkyDedupArgs da; da.key_lo = (sky_u64*)key_lo; da.key_hi = (sky_u64*)key_hi; da.first = (sky_u64*)first; da.slot_mask = (1u << slots_log2) - 1u;
         da.fps = fps.data(); da.seg_total = &seg_prefix[n]; da.max_segs = slots; da.seg_base = seg_base; da.seg_slot = seg_slot.data();
