@@ -139,6 +139,10 @@ def main():
                                                             "one destination worker process (its lanes share the segment store)")
     ap.add_argument("--dedup-store", choices=["memory", "files"], default="memory", help="--dedup-wire: where the destination keeps literal segments -- in the "
                     "one worker process (memory) or in files of the chunk directory shared by --workers processes")
+    ap.add_argument("--dst-consume", action="store_true", help="stand in for write_object_store + the daemon's clean-up: every decoded chunk is checked (size; MD5 of "
+                    "one in eight -- the destination operator has compared every chunk's device-side digest with the sender's already) and DELETED as it "
+                    "arrives, which is what frees the destination's page-locked slot files (shm_arena.LinkSlots) for the next chunks")
+    ap.add_argument("--out-slots", type=int, default=-1, help="slot files per destination lane (-1 = the operator's default, 0 = plain writes)")
     ap.add_argument("--dst-depth", type=int, default=0, help="pipeline lanes per destination worker (0 = the operator's default)")
     ap.add_argument("--src-depth", type=int, default=0, help="pipeline lanes per source worker (0 = the operator's default)")
     a = ap.parse_args()
@@ -196,7 +200,8 @@ def main():
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
                                 max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, pipeline_depth=a.src_depth or None, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
-                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None, **kw)
+                                   max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None,
+                                   out_slots=None if a.out_slots < 0 else a.out_slots, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
         go = threading.Event()
@@ -244,15 +249,25 @@ def main():
                     trace["sent"].append(time.perf_counter())
                 hip_sender.drain_releases(sock)         # slots go back when the peer has acknowledged their bytes, not when sendfile returns
 
+        consumed = {"n": 0, "hashed": 0}
+
         def wait_decoded(n):
             got = 0
             while got < n and not err_ev.is_set():
                 try:
-                    dq_out.q.get(timeout=0.2)
+                    cr = dq_out.q.get(timeout=0.2)
                     got += 1
                     trace["decoded"].append(time.perf_counter())
                 except pyqueue.Empty:
-                    pass
+                    continue
+                if a.dst_consume:                      # write_object_store's view of the chunk, then the daemon's unlink
+                    f = dst / f"{cr.chunk.chunk_id}.chunk"
+                    assert f.stat().st_size == cr.chunk.chunk_length_bytes, f"{f.name}: {f.stat().st_size} bytes"
+                    if a.context != "null" and consumed["n"] % 8 == 0:
+                        assert hashlib.md5(f.read_bytes()).digest() == digests[cr.chunk.chunk_id], f"{f.name}: wrong bytes"
+                        consumed["hashed"] += 1
+                    consumed["n"] += 1
+                    f.unlink()
             return got
 
         op.start_workers()
@@ -288,7 +303,7 @@ def main():
         rx.join(60)
         assert not err_ev.is_set(), err_q.get() if not err_q.empty() else "operator error"
         assert n_dec == a.chunks and n_rx == total
-        if a.context != "null":           # every chunk that arrived, hashed on all the cores the container may use
+        if a.context != "null" and not a.dst_consume:           # every chunk that arrived, hashed on all the cores the container may use
             from concurrent.futures import ThreadPoolExecutor
 
             def check(cr):
@@ -314,7 +329,9 @@ def main():
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
                           "max_batch": a.max_batch, "src_depth": a.src_depth or None, "dst_depth": a.dst_depth or None, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
-                          "status_records": len(status_records), "verified": a.context != "null"}))
+                          "status_records": len(status_records), "verified": a.context != "null",
+                          "dst_consume": ({"chunks_deleted_on_arrival": consumed["n"], "hashed_on_the_cpu": consumed["hashed"]} if a.dst_consume else None),
+                          "out_slots": None if a.out_slots < 0 else a.out_slots}))
 
 
 if __name__ == "__main__":

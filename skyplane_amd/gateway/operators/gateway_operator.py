@@ -507,6 +507,10 @@ class GatewayHipCompress(GatewayOperator):
             # (the file stays while a pointer into it may still be waiting for its sender; the chunk directory is wiped at daemon start)
             w.arena.close(unlink=not any(o is not None and o.exists() for o in w._owner))
         self._tls.writer, self._tls.old_writers = None, []
+        ls = getattr(self._tls, "link_slots", None)
+        if ls is not None:
+            ls.close()
+            self._tls.link_slots = None
         if self._ctx is not None:
             self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
@@ -532,9 +536,14 @@ class GatewayHipDecompress(GatewayHipCompress):
     GatewayHipCompress; there is no CPU fallback.
     """
 
-    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, dedup_store: str = "memory", **kwargs):
+    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, dedup_store: str = "memory", out_slots: Optional[int] = None, **kwargs):
         super().__init__(*args, **kwargs)
         self.verify_md5 = verify_md5
+        # raw side of the hand-off (round 5): decoded chunks are written by the device into page-locked slot FILES and published as hard links
+        # (gateway/shm_arena.py::LinkSlots) instead of going pinned staging -> write() -> page cache.  Slots per lane: None = max_batch with the
+        # "arena" hand-off (a batch in the making while the previous one's chunks are being uploaded and deleted), 0 with "files"; the slot size is the
+        # chunk length of the lane's first batch (other lengths take the write path).
+        self.out_slots = (self.max_batch if self.handoff == "arena" else 0) if out_slots is None else int(out_slots)
         assert dedup_store in ("memory", "files")
         self.dedup_store = dedup_store         # "files": the segment store lives in the chunk directory and several worker processes share it
         # dedup on the wire (dedup_wire.py): payloads that are recipes are rebuilt from their literal stream and the segments earlier chunks
@@ -677,6 +686,36 @@ class GatewayHipDecompress(GatewayHipCompress):
                 po += (max(r, 1) + 255) & ~255
         else:
             payloads = [pl.view if pl.arena is not None else p.read_bytes() for p, pl in zip(paths, opened)]
+        # decoded chunks that fit a free slot file are written THERE by the device (and published as a hard link below): no write() of the chunk
+        link = self._link_slots(ctx, chunk_lens)
+        slot_of = {}
+        if link is not None:
+            fit = [j for j, r in enumerate(chunk_lens) if r == link.size]
+            for j, sl in zip(fit, link.take(len(fit))):
+                slot_of[j] = sl
+        try:
+            return self._decode_and_publish(ctx, chunk_reqs, todo, paths, payloads, sizes, chunk_lens, into, pinned, oks, trace, link, slot_of)
+        except BaseException:
+            for sl in slot_of.values():
+                link.give_back(sl)
+            raise
+
+    def _link_slots(self, ctx, chunk_lens) -> Optional["shm_arena.LinkSlots"]:
+        """This lane's slot files (made on first use, sized by the first batch's chunk length, page-locked through the lane's context)."""
+        if self.out_slots <= 0 or not chunk_lens:
+            return None
+        ls = getattr(self._tls, "link_slots", None)
+        if ls is None:
+            size = max(chunk_lens)
+            if size <= 0:
+                return None
+            tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
+            ls = shm_arena.LinkSlots(self.chunk_store.get_chunk_file_path("x").parent, tag, size, self.out_slots)
+            ls.register(ctx)
+            self._tls.link_slots = ls
+        return ls
+
+    def _decode_and_publish(self, ctx, chunk_reqs, todo, paths, payloads, sizes, chunk_lens, into, pinned, oks, trace, link, slot_of) -> List[bool]:
         # a payload is an LZ4 frame of the chunk, or a recipe whose literal stream is one (dedup_wire.py): one batched decode for both kinds
         recipes = [None] * len(todo)
         frames, raw_lens = list(payloads), list(chunk_lens)
@@ -695,6 +734,10 @@ class GatewayHipDecompress(GatewayHipCompress):
         want_dec = want and any(recipes[j] is None for j in dec)      # the digest of a literal stream is of no use (and costs a whole MD5 chain)
         kwargs = {"want_md5": True} if want_dec else {}
         if into is not None:
+            # (a frame decodes into its slot file's pages; a recipe's decode yields its literal stream, which goes to staging -- the REBUILT chunk goes to the slot)
+            for j in dec:
+                if recipes[j] is None and j in slot_of:
+                    into[j] = link.views[slot_of[j]]
             kwargs["into"] = [into[j] for j in dec]
         datas, digests = [np.zeros(0, np.uint8)] * len(todo), [None] * len(todo)
         if trace:
@@ -722,7 +765,9 @@ class GatewayHipDecompress(GatewayHipCompress):
             cid_j = chunk_reqs[todo[j]].chunk.chunk_id
             try:
                 slot = None
-                if reb_arena is not None:
+                if j in slot_of:
+                    slot = link.views[slot_of[j]]
+                elif reb_arena is not None:
                     slot = reb_arena[reb_pos:reb_pos + rec.raw_len]
                     reb_pos += (rec.raw_len + 255) & ~255
                 chunk = self._rebuild(cid_j, rec, datas[j], out=slot)
@@ -745,6 +790,8 @@ class GatewayHipDecompress(GatewayHipCompress):
             trace.append(time.perf_counter())
         for j, (i, p, data, dig, size) in enumerate(zip(todo, paths, datas, digests, sizes)):
             if not ready[j]:
+                if j in slot_of:
+                    link.give_back(slot_of.pop(j))
                 continue                               # re-queued by the worker loop; its literals are already in the store
             cr = chunk_reqs[i]
             cid = cr.chunk.chunk_id
@@ -754,10 +801,18 @@ class GatewayHipDecompress(GatewayHipCompress):
             if exp is not None and dig != exp:
                 raise ValueError(f"[Gateway] chunk {cid}: checksum mismatch, md5 {dig.hex()} != {exp.hex()}")
             final = self.chunk_store.get_chunk_file_path(cid)
-            tmp = final.with_suffix(".dectmp")
-            with open(tmp, "wb") as f:
-                f.write(data)
-            os.replace(tmp, final)
+            sl = slot_of.pop(j, None)
+            if sl is not None and isinstance(data, np.ndarray) and data.size == link.size and data.ctypes.data == link.views[sl].ctypes.data:
+                link.publish(sl, final)                # the chunk's bytes are already in the file's pages: a hard link makes them <id>.chunk
+            else:
+                if sl is not None:                     # (a context that does not decode in place -- emulator -- : one copy into the slot's pages)
+                    link.views[sl][:len(data)] = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+                    link.publish(sl, final)
+                else:
+                    tmp = final.with_suffix(".dectmp")
+                    with open(tmp, "wb") as f:
+                        f.write(data)
+                    os.replace(tmp, final)
             p.unlink()
             meta = {"compressed_size_bytes": size, "uncompressed_size_bytes": len(data)}
             if dig is not None:

@@ -287,3 +287,105 @@ def sendfile_payload(sock, path) -> int:
             raise ConnectionError(f"socket closed after {sent} of {p.length} payload bytes")
         sent += n
     return sent
+
+
+# ---- destination, raw side: the decoded chunk's file IS page-locked memory (round 5) ----
+class LinkSlots:
+    """`n_slots` files of exactly `size` bytes in the chunk directory, each mapped MAP_SHARED (and page-locked once by the process that owns the device
+    context: `register`).  gpu_decompress lets the device write a decoded chunk of `size` bytes straight into a free slot's pages and PUBLISHES it by
+    hard-linking the slot file to ``<id>.chunk`` (temporary name + rename: complete when visible) -- what the reference's neighbours
+    (GatewayWaitReceiver's size test, write_object_store's ``upload_object(src_file_path=...)``, gateway_operator.py:125-149, :625-645) then see is an
+    ordinary file of the right length whose bytes never passed through a ``write()``.  The daemon deleting ``<id>.chunk`` when the chunk is done drops
+    the link count of the slot's inode back to 1, which is what marks the slot free: no other IPC.  Chunks of another length (an object's short tail)
+    and times when every slot is still waiting for its upload take the plain write path -- slower, never wrong.
+
+    Why only the destination: the source side's ``<id>.chunk`` is created by ``download_object(..., dst_file_path)`` of whichever object-store interface
+    serves the bucket (s3_interface.py:156-192 and siblings), every one of which opens its destination with mode "wb" -- a truncation, which frees the
+    pages a registration pinned.  Page-locked source chunks would need a change in each interface, outside this path's boundary."""
+
+    def __init__(self, directory, tag: str, size: int, n_slots: int):
+        self.dir, self.size, self.n = Path(directory), int(size), int(n_slots)
+        assert self.size > 0 and self.n > 0
+        self.paths: List[Path] = []
+        self._maps: List[mmap.mmap] = []
+        self.views: List[np.ndarray] = []
+        self._busy = [False] * self.n
+        self._next = 0
+        self._lock = threading.Lock()
+        self._registered_by = None
+        for k in range(self.n):
+            p = self.dir / f"_outslot_{tag}_{k}.bin"
+            fd = os.open(p, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o644)
+            try:
+                os.ftruncate(fd, self.size)
+                mm = mmap.mmap(fd, self.size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+            finally:
+                os.close(fd)
+            self.paths.append(p)
+            self._maps.append(mm)
+            self.views.append(np.frombuffer(mm, np.uint8))
+
+    def register(self, ctx) -> bool:
+        """Page-lock every slot through ctx (once; a context without register_host -- emulator, null device -- needs none)."""
+        if self._registered_by is not None or not hasattr(ctx, "register_host"):
+            return False
+        for v in self.views:
+            v[::4096] = 0                      # touch: the pages exist before they are pinned
+            ctx.register_host(v)
+        self._registered_by = ctx
+        return True
+
+    def take(self, want: int) -> List[int]:
+        got: List[int] = []
+        with self._lock:
+            for k in range(self.n):
+                if len(got) >= want:
+                    break
+                i = (self._next + k) % self.n
+                if self._busy[i]:
+                    continue
+                try:
+                    if os.stat(self.paths[i]).st_nlink != 1:      # still published: its chunk has not been uploaded and deleted yet
+                        continue
+                except FileNotFoundError:
+                    continue
+                self._busy[i] = True
+                got.append(i)
+            if got:
+                self._next = (got[-1] + 1) % self.n
+        return got
+
+    def publish(self, slot: int, final: Path):
+        tmp = final.with_name(final.name + ".lnk")
+        try:
+            os.unlink(tmp)
+        except FileNotFoundError:
+            pass
+        os.link(self.paths[slot], tmp)
+        os.replace(tmp, final)
+        with self._lock:
+            self._busy[slot] = False
+
+    def give_back(self, slot: int):
+        with self._lock:
+            self._busy[slot] = False
+
+    def close(self):
+        ctx, self._registered_by = self._registered_by, None
+        for v, mm, p in zip(self.views, self._maps, self.paths):
+            if ctx is not None and hasattr(ctx, "unregister_host"):
+                try:
+                    ctx.unregister_host(v)
+                except Exception:
+                    pass
+            try:
+                p.unlink()                     # a published link keeps the inode (and its bytes) alive for whoever still reads it
+            except FileNotFoundError:
+                pass
+        self.views = []
+        for mm in self._maps:
+            try:
+                mm.close()
+            except (BufferError, ValueError):
+                pass
+        self._maps = []

@@ -359,6 +359,79 @@ def test_decompress_operator_waits_decodes_verifies(tmp_path, monkeypatch):
     assert len(recs) == n and sum("md5_hex" in r for r in recs) >= 5
 
 
+class _InPlaceDecodeContext(_ArenaContext):
+    """Destination double WITH the staging interface: decompress_batch writes into `into` and returns views of it (what SkyHipContext does by DMA), and
+    logs every register_host so that the test can see the slot files being page-locked once."""
+
+    def register_host(self, buf):
+        Path(os.environ["SKYTEST_DEVLOG"]).open("a").write(f"register {buf.size}\n")
+
+    def unregister_host(self, buf):
+        pass
+
+    def decompress_batch(self, frames, raw_lens, want_md5=False, into=None):
+        outs = []
+        for f, n, o in zip(frames, raw_lens, into):
+            d = np.frombuffer(ref.lz4f_decompress(bytes(f), n), np.uint8)
+            o[: d.size] = d
+            outs.append(o[: d.size])
+        return (outs, [hashlib.md5(o.tobytes()).digest() for o in outs]) if want_md5 else outs
+
+
+def test_decoded_chunks_are_published_as_hard_links_to_page_locked_slot_files(tmp_path, monkeypatch):
+    """Raw side of the destination hand-off: the device writes a decoded chunk into a slot FILE's pages and
+    <id>.chunk is a hard link to it -- an ordinary file of the right length for GatewayWaitReceiver / write_object_store (gateway_operator.py:125-149,
+    :625-645), no write() of the chunk.  Deleting <id>.chunk (what the daemon does when the chunk is done) frees the slot; a chunk of another length and a
+    batch that finds no free slot take the plain write path."""
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    size = 40_000
+    src, _, _, reqs = _make_store(tmp_path / "src", 7, size=size)
+    short = (reqs[6][0], reqs[6][1][:12_345])                                  # an object's short tail
+    short[0].chunk.chunk_length_bytes = len(short[1])
+    reqs[6] = short
+    dst = ChunkStore(tmp_path / "dst" / "chunks")
+    q_in, q_out = GatewayQueue(), GatewayQueue()
+    dst.add_partition("0", q_in)
+    err_ev, err_q = Event(), Queue()
+    op = GatewayHipDecompress("gpu_decompress_0", "local:dst", q_in, q_out, err_ev, err_q, dst, n_processes=1, max_batch=4, device_ids=[0],
+                              context_factory=lambda d, mc, mb: _InPlaceDecodeContext(d, mc, mb), out_slots=3)
+    op.worker_id = 0
+    for cr, data in reqs:
+        cr.chunk.md5_hash = hashlib.md5(data).hexdigest()
+        dst.get_compressed_file_path(cr.chunk.chunk_id).write_bytes(ref.lz4f_compress_port(data))
+    first = [cr for cr, _ in reqs[:4]]
+    assert op.process_batch(first) == [True] * 4
+    slot_files = sorted((tmp_path / "dst" / "chunks").glob("_outslot_*"))
+    assert len(slot_files) == 3 and all(f.stat().st_size == size for f in slot_files)
+    inodes = {f.stat().st_ino for f in slot_files}
+    linked = [dst.get_chunk_file_path(cr.chunk.chunk_id).stat().st_ino in inodes for cr in first]
+    assert linked == [True, True, True, False]                                  # three slots: the fourth chunk was written the plain way
+    for cr, data in reqs[:4]:
+        f = dst.get_chunk_file_path(cr.chunk.chunk_id)
+        assert f.read_bytes() == data and f.stat().st_size == size               # a file like any other for whoever uploads it
+        assert not dst.get_compressed_file_path(cr.chunk.chunk_id).exists()
+    log = (tmp_path / "dev.log").read_text().splitlines()
+    assert log.count(f"register {size}") == 3                                    # page-locked once, when the slots were made
+    # nothing is free while the chunks wait for their upload ...
+    assert op.process_batch([reqs[4][0]]) == [True]
+    assert dst.get_chunk_file_path(reqs[4][0].chunk.chunk_id).stat().st_ino not in inodes
+    # ... the daemon deleting two finished chunks frees two slots (link count back to 1); the short tail never fits one
+    dst.get_chunk_file_path(first[0].chunk.chunk_id).unlink()
+    dst.get_chunk_file_path(first[2].chunk.chunk_id).unlink()
+    assert op.process_batch([reqs[5][0], reqs[6][0]]) == [True, True]
+    assert dst.get_chunk_file_path(reqs[5][0].chunk.chunk_id).stat().st_ino in inodes
+    assert dst.get_chunk_file_path(reqs[6][0].chunk.chunk_id).stat().st_ino not in inodes
+    assert dst.get_chunk_file_path(reqs[5][0].chunk.chunk_id).read_bytes() == reqs[5][1]
+    assert dst.get_chunk_file_path(reqs[6][0].chunk.chunk_id).read_bytes() == reqs[6][1]
+    assert dst.get_chunk_file_path(first[1].chunk.chunk_id).read_bytes() == reqs[1][1]      # a published chunk is not touched by later batches
+    assert log.count(f"register {size}") == 3
+    op.worker_exit(0)
+    assert not list((tmp_path / "dst" / "chunks").glob("_outslot_*"))
+    assert dst.get_chunk_file_path(first[1].chunk.chunk_id).read_bytes() == reqs[1][1]      # ... nor by the slots going away
+
+
 def test_decompress_operator_checksum_mismatch_is_an_error(tmp_path, monkeypatch):
     from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
 
