@@ -150,6 +150,27 @@ double skyhip_decompress_ms(skyhip_ctx* ctx, int reset);   /* accumulated device
 int  skyhip_cdc_results(skyhip_ctx* ctx, int n, uint64_t* cut_prefix /* n+1 */, uint32_t* cuts, size_t cuts_cap,
                         uint8_t* fps, uint64_t* first_seen, uint64_t* seg_base_index);
 
+/* Dedup on the wire, source side (skyplane_amd/gateway/dedup_wire.py; no reference counterpart: SURVEY 8f item 4).  Valid right after a
+ * skyhip_process_batch call with SKYHIP_F_CDC | SKYHIP_F_DEDUP over the same n <= max_batch chunks: for every chunk i the concatenation of its NEW
+ * segments (first_seen == own index) -- the chunk's literal stream -- is put together ON THE DEVICE from the chunks still resident in the context's
+ * staging area and compressed into one LZ4 frame in out[i] (out_cap[i] >= skyhip_frame_bound(in_len[i]); pinned memory makes the copy asynchronous).
+ * lit_len[i] = raw length of the stream.  out_len[i] = 0 for a chunk without duplicates (lit_len == in_len: the frame the first call made IS its
+ * literal stream) and for one without new segments. */
+int  skyhip_dedup_literals(skyhip_ctx* ctx, int n, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* lit_len);
+
+/* Dedup on the wire, destination side (skyplane_amd/gateway/dedup_wire.py): a recipe's chunk is put together ON THE DEVICE from literal streams that stay
+ * there.  skyhip_dev_alloc / skyhip_dev_free: device memory the caller owns (the segment store's literal streams).  skyhip_decompress_to_device: like
+ * skyhip_decompress_batch, but frame i is decoded into DEVICE memory dst[i] (>= out_cap[i] bytes) and nothing comes back to the host but lengths and
+ * status.  skyhip_gather_md5: chunk i := the runs run_prefix[i] .. run_prefix[i+1] back to back, run k being run_len[k] bytes at DEVICE address
+ * run_src[k]; the chunk is copied to host out[i] (pinned memory: asynchronously, beside the digest) and md5[i] (may be NULL) is its digest --
+ * what lz4.frame.decompress + the "# todo check hash" of gateway_receiver.py:195-231 amount to for a chunk that travelled as a recipe. */
+int  skyhip_dev_alloc(skyhip_ctx* ctx, size_t bytes, void** out);
+int  skyhip_dev_free(skyhip_ctx* ctx, void* p);
+int  skyhip_decompress_to_device(skyhip_ctx* ctx, int n, const uint8_t* const* in, const size_t* in_len, void* const* dst, const size_t* out_cap,
+                                 size_t* out_len, int32_t* status);
+int  skyhip_gather_md5(skyhip_ctx* ctx, int n, const uint64_t* run_prefix /* n+1 */, const uint64_t* run_src, const uint32_t* run_len,
+                       uint8_t* const* out, const size_t* out_cap, size_t* out_len, uint8_t (*md5)[16]);
+
 /* Forget every fingerprint in the dedup table. */
 int  skyhip_dedup_reset(skyhip_ctx* ctx);
 

@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "scripts"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+import numpy as np  # noqa: E402
 from e2e_loopback import receiver_main  # noqa: E402  (the deferred receiver process)
 from skyplane_amd import synth  # noqa: E402
 from skyplane_amd.chunk import Chunk, ChunkRequest  # noqa: E402
@@ -162,7 +163,11 @@ def main():
         dq_in, dq_out = GatewayQueue(), GatewayQueue()
         dst_store.add_partition("0", dq_in)
         base = synth.mixed_chunks(4, size, config_id=4)
-        dd_stream = synth.dedup_stream((a.connections + a.chunks) * size, dup_fraction=0.5, config_id=3) if a.dedup_wire else None
+        # --dedup-wire: a 50 %-duplicate stream (half of its 8-64 KiB spans are copies of earlier spans at unaligned offsets).  Generated for at most 128 chunks
+        # and tiled like bench.py --cdc tiles its unit (tile t = the base XOR t: the duplicate structure inside a tile stays, tiles are mutually distinct):
+        # the generator is a Python loop over spans, and 8.6 GiB of it was minutes of set-up around a 5 s measurement
+        DD_TILE = 128
+        dd_stream = synth.dedup_stream(min(a.connections + a.chunks, DD_TILE) * size, dup_fraction=0.5, config_id=3) if a.dedup_wire else None
         digests = {}
 
         # Without --dedup-wire the stream is four chunk contents in turn: they are written and hashed ONCE and every chunk file is a hard link (the operators only
@@ -182,7 +187,8 @@ def main():
                 os.link(proto[k][0], src.get_chunk_file_path(cid))
                 digests[cid] = proto[k][1]
             else:
-                data = dd_stream[i * size:(i + 1) * size].tobytes()
+                k, t = i % DD_TILE, i // DD_TILE
+                data = (dd_stream[k * size:(k + 1) * size] ^ np.uint8(t & 0xFF)).tobytes() if t else dd_stream[k * size:(k + 1) * size].tobytes()
                 src.get_chunk_file_path(cid).write_bytes(data)
                 digests[cid] = hashlib.md5(data).digest()
             return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
@@ -249,7 +255,19 @@ def main():
                     trace["sent"].append(time.perf_counter())
                 hip_sender.drain_releases(sock)         # slots go back when the peer has acknowledged their bytes, not when sendfile returns
 
-        consumed = {"n": 0, "hashed": 0}
+        consumed = {"n": 0, "hashed": 0, "bad": []}
+        from concurrent.futures import ThreadPoolExecutor
+        consumers = ThreadPoolExecutor(4) if a.dst_consume else None      # (stat / read / hashlib / unlink all release the GIL)
+
+        def consume(cr, do_hash):                      # write_object_store's view of the chunk, then the daemon's unlink
+            f = dst / f"{cr.chunk.chunk_id}.chunk"
+            try:
+                ok = f.stat().st_size == cr.chunk.chunk_length_bytes and (not do_hash or hashlib.md5(f.read_bytes()).digest() == digests[cr.chunk.chunk_id])
+                if not ok:
+                    consumed["bad"].append(f.name)
+                f.unlink()
+            except BaseException as e:      # noqa: BLE001
+                consumed["bad"].append(f"{f.name}: {e!r}")
 
         def wait_decoded(n):
             got = 0
@@ -260,14 +278,11 @@ def main():
                     trace["decoded"].append(time.perf_counter())
                 except pyqueue.Empty:
                     continue
-                if a.dst_consume:                      # write_object_store's view of the chunk, then the daemon's unlink
-                    f = dst / f"{cr.chunk.chunk_id}.chunk"
-                    assert f.stat().st_size == cr.chunk.chunk_length_bytes, f"{f.name}: {f.stat().st_size} bytes"
-                    if a.context != "null" and consumed["n"] % 8 == 0:
-                        assert hashlib.md5(f.read_bytes()).digest() == digests[cr.chunk.chunk_id], f"{f.name}: wrong bytes"
-                        consumed["hashed"] += 1
+                if consumers is not None:
+                    do_hash = a.context != "null" and consumed["n"] % 8 == 0
+                    consumed["hashed"] += int(do_hash)
                     consumed["n"] += 1
-                    f.unlink()
+                    consumers.submit(consume, cr, do_hash)
             return got
 
         op.start_workers()
@@ -287,6 +302,9 @@ def main():
         for cr in main_reqs:
             src.add_chunk_request(cr)
         n_dec = wait_decoded(a.chunks)
+        if consumers is not None:
+            consumers.shutdown(wait=True)              # the clock stops when the last chunk has been checked and deleted
+            assert not consumed["bad"], consumed["bad"][:4]
         elapsed = time.perf_counter() - t0
         for t in threads:
             t.join(60)

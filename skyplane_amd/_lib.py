@@ -14,7 +14,8 @@ EXPORTS = (
     "skyhip_cdc_results", "skyhip_dedup_reset", "skyhip_get_timing", "skyhip_reset_timing", "skyhip_selftest", "skyhip_strerror",
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
     "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault", "skyhip_host_register", "skyhip_host_unregister",
-    "skyhip_debug_guard_alloc", "skyhip_debug_guard_free", "skyhip_debug_guard_probe",
+    "skyhip_debug_guard_alloc", "skyhip_debug_guard_free", "skyhip_debug_guard_probe", "skyhip_dedup_literals",
+    "skyhip_dev_alloc", "skyhip_dev_free", "skyhip_decompress_to_device", "skyhip_gather_md5",
 )
 
 
@@ -76,6 +77,16 @@ def load() -> C.CDLL:
     lib.skyhip_cdc_results.restype = C.c_int
     lib.skyhip_dedup_reset.argtypes = [vp]
     lib.skyhip_dedup_reset.restype = C.c_int
+    lib.skyhip_dedup_literals.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    lib.skyhip_dedup_literals.restype = C.c_int
+    lib.skyhip_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.skyhip_dev_alloc.restype = C.c_int
+    lib.skyhip_dev_free.argtypes = [vp, vp]
+    lib.skyhip_dev_free.restype = C.c_int
+    lib.skyhip_decompress_to_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.skyhip_decompress_to_device.restype = C.c_int
+    lib.skyhip_gather_md5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.skyhip_gather_md5.restype = C.c_int
     lib.skyhip_get_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.skyhip_get_timing.restype = None
     lib.skyhip_reset_timing.argtypes = [vp]

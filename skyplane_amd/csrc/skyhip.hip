@@ -97,6 +97,9 @@ extern "C" __global__ void __launch_bounds__(256) sky_seg_prefix(SkySegPrefixArg
 }
 extern "C" __global__ void __launch_bounds__(256) sky_seg_desc(SkySegDescArgs a) { sky_seg_desc_body(a); }
 extern "C" __global__ void __launch_bounds__(64) SKY_MD5_KERNEL_ATTR sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }      // <= 128 VGPRs like sky_md5_chunks: runs beside the compressor
+extern "C" __global__ void __launch_bounds__(256) sky_gather_runs(SkyRunArgs a) { sky_gather_runs_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_lit_plan(SkyLitArgs a) { sky_lit_plan_body(a); }
+extern "C" __global__ void __launch_bounds__(256) sky_lit_gather(SkyLitArgs a) { sky_lit_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_insert(SkyDedupArgs a) { sky_dedup_insert_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_dedup_resolve(SkyDedupArgs a) { sky_dedup_resolve_body(a); }
 #endif
@@ -284,7 +287,9 @@ struct skyhip_ctx {
     int lz4s_grid = 0;            // workgroups of the slice-parallel compressor = CUs of the device (141 KiB of LDS each: one per CU)
     DevBuf<sky_u64> d_blk_dst[2];
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
-    DevBuf<uint8_t> d_stage_in, d_stage_out;
+    DevBuf<uint8_t> d_stage_in, d_stage_out, d_lit;
+    DevBuf<sky_u64> d_run_src, d_run_dst; DevBuf<uint32_t> d_run_len;      // skyhip_gather_md5
+    int stage_n = 0; size_t stage_in_stride = 0; std::vector<uint64_t> stage_len;      // the chunks skyhip_process_batch left in d_stage_in (skyhip_dedup_literals)
     hipStream_t s_up = nullptr, s_down = nullptr;
     std::vector<hipEvent_t> ev_up;    // upload-complete event per LZ4 sub-batch of a group (grow-only)
     std::vector<void*> host_allocs;   // skyhip_host_alloc'ed blocks still alive (freed by skyhip_destroy at the latest)
@@ -487,7 +492,7 @@ void skyhip_destroy(skyhip_ctx* c) {
         if (c->ev_fr_done[k]) (void)hipEventDestroy(c->ev_fr_done[k]);
     }
     c->d_queue.release();
-    c->d_stage_in.release(); c->d_stage_out.release();
+    c->d_stage_in.release(); c->d_stage_out.release(); c->d_lit.release(); c->d_run_src.release(); c->d_run_dst.release(); c->d_run_len.release();
     for (hipEvent_t e : c->ev_up) (void)hipEventDestroy(e);
     c->ev_up.clear();
     for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -854,12 +859,57 @@ int skyhip_process_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const s
     const hipError_t e1 = hipStreamSynchronize(c->s_up), e2 = hipStreamSynchronize(c->s_down);
     if (he == hipSuccess && e1 != hipSuccess) { he = e1; what = "hipStreamSynchronize(s_up)"; }
     if (he == hipSuccess && e2 != hipSuccess) { he = e2; what = "hipStreamSynchronize(s_down)"; }
+    c->stage_n = 0;
     if (rc != SKYHIP_OK) return rc;
     if (he != hipSuccess) {
         snprintf(c->hip_err, sizeof(c->hip_err), "%s: %s (process_batch)", what, hipGetErrorString(he));
         return he == hipErrorOutOfMemory ? SKYHIP_E_NOMEM : SKYHIP_E_HIP;
     }
+    if ((size_t)n <= group) {      // one group: every chunk of the call is still in the staging area, chunk i at i * in_stride
+        c->stage_n = n; c->stage_in_stride = in_stride;
+        c->stage_len.assign(in_len, in_len + n);
+    }
     return SKYHIP_OK;
+}
+
+int skyhip_dedup_literals(skyhip_ctx* c, int n, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* lit_len) {
+#ifndef SKY_WITH_CDC
+    (void)c; (void)n; (void)out; (void)out_cap; (void)out_len; (void)lit_len;
+    return SKYHIP_E_INVAL;
+#else
+    if (!c || n <= 0 || !out || !out_cap || !out_len || !lit_len) return SKYHIP_E_INVAL;
+    // valid only right after the skyhip_process_batch call (CDC + DEDUP, one group) whose chunks these are
+    if (c->stage_n != n || (uint32_t)n != c->cdc.last_n || !c->cdc.last_dedup || c->cdc.pending) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    for (int i = 0; i < n; i++) if (!out[i] || out_cap[i] < skyhip_frame_bound((size_t)c->stage_len[i])) return SKYHIP_E_CAP;
+    HIPCHK(c, c->d_lit.ensure(c->stage_in_stride * (size_t)n + 256));
+    std::vector<uint32_t> h_lit((size_t)n);
+    int rc = sky_cdc_literals(&c->cdc, c->s_cdc, c->d_stage_in.p, (uint32_t)n, c->d_lit.p, c->stage_in_stride, h_lit.data(), c->hip_err, sizeof c->hip_err);
+    if (rc) return rc;
+    // the literal streams that are worth a frame of their own: a chunk without duplicates keeps the frame the first call made (its literal stream IS the chunk)
+    std::vector<uint64_t> off, len, ooff, ocap, flen;
+    std::vector<int> idx;
+    const size_t out_stride = (skyhip_frame_bound(c->stage_in_stride) + 255) & ~(size_t)255;
+    for (int i = 0; i < n; i++) {
+        lit_len[i] = h_lit[i]; out_len[i] = 0;
+        if (h_lit[i] == 0 || h_lit[i] == c->stage_len[i]) continue;
+        idx.push_back(i);
+        off.push_back(c->stage_in_stride * (uint64_t)i); len.push_back(h_lit[i]);
+        ooff.push_back(out_stride * (uint64_t)(idx.size() - 1)); ocap.push_back(out_stride);
+    }
+    if (idx.empty()) return SKYHIP_OK;
+    flen.resize(idx.size());
+    HIPCHK(c, c->d_stage_out.ensure(out_stride * idx.size() + 256));
+    rc = sky_process_impl(c, (int)idx.size(), c->d_lit.p, off.data(), len.data(), c->d_stage_out.p, ooff.data(), ocap.data(), flen.data(), nullptr, SKYHIP_F_LZ4, nullptr);
+    c->stage_n = n;      // (sky_process_impl does not touch the staging area of the chunks)
+    if (rc) return rc;
+    for (size_t k = 0; k < idx.size(); k++) {
+        out_len[idx[k]] = (size_t)flen[k];
+        HIPCHK(c, hipMemcpyAsync(out[idx[k]], c->d_stage_out.p + ooff[k], flen[k], hipMemcpyDeviceToHost, c->s_down));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_down));
+    return SKYHIP_OK;
+#endif
 }
 
 int skyhip_decompress_device(skyhip_ctx* c, int n, const void* d_in, const uint64_t* in_off, const uint64_t* in_len, void* d_out,
@@ -936,6 +986,95 @@ int skyhip_decompress_batch_md5(skyhip_ctx* c, int n, const uint8_t* const* in, 
 int skyhip_decompress_batch(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, uint8_t* const* out, const size_t* out_cap,
                             size_t* out_len, int32_t* status) {
     return skyhip_decompress_batch_md5(c, n, in, in_len, out, out_cap, out_len, status, nullptr);
+}
+
+int skyhip_dev_alloc(skyhip_ctx* c, size_t bytes, void** out) {
+    if (!c || !out || bytes == 0) return SKYHIP_E_INVAL;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipMalloc(out, bytes));
+    return SKYHIP_OK;
+}
+int skyhip_dev_free(skyhip_ctx* c, void* p) {
+    if (!c) return SKYHIP_E_INVAL;
+    if (!p) return SKYHIP_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipFree(p));
+    return SKYHIP_OK;
+}
+
+int skyhip_decompress_to_device(skyhip_ctx* c, int n, const uint8_t* const* in, const size_t* in_len, void* const* dst, const size_t* out_cap, size_t* out_len,
+                                int32_t* status) {
+    if (!c || n < 0) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    if (!in || !in_len || !dst || !out_cap || !out_len) return SKYHIP_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<uint64_t> ioff(n), ilen(n), ooff(n), ocap(n), olen(n);
+    uint64_t itot = 0;
+    for (int i = 0; i < n; i++) {
+        if ((in_len[i] && !in[i]) || (out_cap[i] && !dst[i])) return SKYHIP_E_INVAL;
+        ioff[i] = itot; ilen[i] = in_len[i]; itot += (in_len[i] + 255) & ~(uint64_t)255;
+        ooff[i] = (uint64_t)(uintptr_t)dst[i]; ocap[i] = out_cap[i];      // the decoder adds these to a null base: absolute device addresses
+    }
+    HIPCHK(c, c->dec.d_stage_in.ensure(itot + 256));
+    for (int i = 0; i < n; i++)
+        if (in_len[i]) HIPCHK(c, hipMemcpyAsync(c->dec.d_stage_in.p + ioff[i], in[i], in_len[i], hipMemcpyHostToDevice, c->s_lz4));
+    const int rc = sky_lz4d_run(&c->dec, c->s_lz4, n, c->dec.d_stage_in.p, ioff.data(), ilen.data(), nullptr, ooff.data(), ocap.data(), olen.data(), status,
+                                &c->dec_ms, c->hip_err, sizeof c->hip_err);
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));
+    for (int i = 0; i < n; i++) out_len[i] = (size_t)olen[i];
+    return rc;
+}
+
+int skyhip_gather_md5(skyhip_ctx* c, int n, const uint64_t* run_prefix, const uint64_t* run_src, const uint32_t* run_len, uint8_t* const* out,
+                      const size_t* out_cap, size_t* out_len, uint8_t (*md5)[16]) {
+#ifndef SKY_WITH_CDC
+    (void)c; (void)n; (void)run_prefix; (void)run_src; (void)run_len; (void)out; (void)out_cap; (void)out_len; (void)md5;
+    return SKYHIP_E_INVAL;
+#else
+    if (!c || n < 0) return SKYHIP_E_INVAL;
+    if (n == 0) return SKYHIP_OK;
+    if (!run_prefix || !out || !out_cap || !out_len || run_prefix[0] != 0) return SKYHIP_E_INVAL;
+    const uint64_t nruns = run_prefix[n];
+    if (nruns && (!run_src || !run_len)) return SKYHIP_E_INVAL;
+    if (nruns > 0x7FFFFFFFull) return SKYHIP_E_TOOBIG;
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<uint64_t> coff(n), clen(n), dst(nruns ? nruns : 1);
+    uint64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        if (run_prefix[i + 1] < run_prefix[i]) return SKYHIP_E_INVAL;
+        uint64_t len = 0;
+        for (uint64_t r = run_prefix[i]; r < run_prefix[i + 1]; r++) len += run_len[r];
+        if (len > c->max_chunk) return SKYHIP_E_TOOBIG;
+        if (len > out_cap[i] || (len && !out[i])) return SKYHIP_E_CAP;
+        coff[i] = tot; clen[i] = len; tot += (len + 255) & ~(uint64_t)255;
+    }
+    HIPCHK(c, c->dec.d_stage_out.ensure(tot + 256));
+    for (int i = 0; i < n; i++) {
+        uint64_t at = (uint64_t)(uintptr_t)(c->dec.d_stage_out.p + coff[i]);
+        for (uint64_t r = run_prefix[i]; r < run_prefix[i + 1]; r++) { dst[r] = at; at += run_len[r]; }
+    }
+    if (nruns) {
+        HIPCHK(c, c->d_run_src.ensure(nruns)); HIPCHK(c, c->d_run_dst.ensure(nruns)); HIPCHK(c, c->d_run_len.ensure(nruns));
+        HIPCHK(c, hipMemcpyAsync(c->d_run_src.p, run_src, nruns * 8, hipMemcpyHostToDevice, c->s_lz4));
+        HIPCHK(c, hipMemcpyAsync(c->d_run_dst.p, dst.data(), nruns * 8, hipMemcpyHostToDevice, c->s_lz4));
+        HIPCHK(c, hipMemcpyAsync(c->d_run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->s_lz4));
+        SkyRunArgs ra; ra.src = c->d_run_src.p; ra.dst = c->d_run_dst.p; ra.len = c->d_run_len.p; ra.n_runs = (uint32_t)nruns;
+        uint32_t wgs = (uint32_t)((nruns + 3) / 4);
+        if (wgs > (uint32_t)c->lz4s_grid * 8u) wgs = (uint32_t)c->lz4s_grid * 8u;
+        hipLaunchKernelGGL(sky_gather_runs, dim3(wgs), dim3(256), 0, c->s_lz4, ra);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));      // (dst lives on this function's stack; and the chunks are whole before anybody reads them)
+    for (int i = 0; i < n; i++) {
+        out_len[i] = (size_t)clen[i];
+        if (clen[i]) HIPCHK(c, hipMemcpyAsync(out[i], c->dec.d_stage_out.p + coff[i], clen[i], hipMemcpyDeviceToHost, c->s_down));      // beside the digest chains
+    }
+    int rc = SKYHIP_OK;
+    if (md5) rc = sky_process_impl(c, n, c->dec.d_stage_out.p, coff.data(), clen.data(), nullptr, nullptr, nullptr, nullptr, md5, SKYHIP_F_MD5, nullptr);
+    HIPCHK(c, hipStreamSynchronize(c->s_down));
+    return rc;
+#endif
 }
 
 double skyhip_decompress_ms(skyhip_ctx* c, int reset) {

@@ -19,6 +19,7 @@ anyway): the destination can only resolve references to segments it has been tol
 from __future__ import annotations
 
 import fcntl
+import ctypes as C
 import mmap
 import os
 import shutil
@@ -71,6 +72,41 @@ def encode_recipe(lane: int, epoch: int, seg_lens, kinds, fps, lit_frame, lit_ra
     segs["len"], segs["kind"], segs["fp"] = seg_lens, kinds, fps
     lit = bytes(lit_frame)
     return _HDR.pack(MAGIC, VERSION, lane & 0xFFFFFFFFFFFFFFFF, epoch, n, int(seg_lens.sum()), int(lit_raw_len), len(lit)) + segs.tobytes() + lit
+
+
+class RecipeParts:
+    """A recipe as (head, literal frame) without the copy that gluing them together costs: `head` = header + segment table (bytes), `frame` = the LZ4
+    frame of the literal stream wherever it already is (a view of pinned staging).  len() and write_to() are what the operator needs of a payload."""
+
+    __slots__ = ("head", "frame")
+
+    def __init__(self, head: bytes, frame):
+        self.head, self.frame = head, frame
+
+    def __len__(self) -> int:
+        return len(self.head) + len(self.frame)
+
+    def write_to(self, f):
+        f.write(self.head)
+        if len(self.frame):
+            f.write(self.frame)
+
+    def __bytes__(self) -> bytes:
+        return self.head + bytes(self.frame)
+
+
+def encode_recipe_parts(lane: int, epoch: int, seg_lens, kinds, fps, lit_frame, lit_raw_len: int) -> RecipeParts:
+    """encode_recipe without copying the literal frame (it is written straight from where the device put it)."""
+    seg_lens = np.asarray(seg_lens, np.uint32)
+    kinds = np.asarray(kinds, np.uint8)
+    fps = np.asarray(fps, np.uint8).reshape(-1, 16)
+    n = seg_lens.size
+    assert kinds.size == n and fps.shape[0] == n
+    assert int(seg_lens[kinds == KIND_LITERAL].sum()) == int(lit_raw_len)
+    segs = np.zeros(n, SEG_DTYPE)
+    segs["len"], segs["kind"], segs["fp"] = seg_lens, kinds, fps
+    frame = lit_frame if isinstance(lit_frame, np.ndarray) else np.frombuffer(bytes(lit_frame), np.uint8)
+    return RecipeParts(_HDR.pack(MAGIC, VERSION, lane & 0xFFFFFFFFFFFFFFFF, epoch, n, int(seg_lens.sum()), int(lit_raw_len), int(frame.size)) + segs.tobytes(), frame)
 
 
 def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
@@ -254,6 +290,77 @@ class SegmentStore:
     def epochs_held(self, lane: int) -> List[int]:
         with self._lock:
             return sorted(k[1] for k in self._segs if k[0] == lane)
+
+
+class DeviceSegmentStore(SegmentStore):
+    """The store of a destination whose chunks are put together ON THE DEVICE (gateway_operator.GatewayHipDecompress, round 5): what a fingerprint leads
+    to is an ADDRESS and a length -- a piece of a literal stream that stayed in device memory where it was decoded -- and both directions work on whole
+    arrays (`put_arrays` / `get_arrays`: one call into csrc/skyhost.c per chunk instead of a dictionary operation per segment under the interpreter
+    lock the destination's lanes share).  Same bounds as SegmentStore (epochs kept per lane, byte budget, idle time); a group that goes takes its map
+    and the buffers it kept alive (hip_ops.DeviceBuffer: the device memory is freed with the last of them) with it."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from skyplane_amd import _hostlib
+
+        self._h = _hostlib.load()
+        self._maps: Dict[Tuple[int, int], list] = {}          # (lane, epoch) -> [native map, [buffers kept alive]]
+
+    def _drop(self, keys):
+        for key in keys:
+            m = self._maps.pop(key, None)
+            if m is not None:
+                self._h.skyhost_map_free(m[0])
+                m[1].clear()
+            self._segs.pop(key, None)
+            self._b.forget(key)
+
+    def put_arrays(self, lane: int, epoch: int, fps: np.ndarray, addrs: np.ndarray, lens: np.ndarray, keep):
+        """fps [n, 16] uint8, addrs [n] uint64, lens [n] uint32: segment k is lens[k] bytes at addrs[k], inside `keep` (kept alive with the group)."""
+        fps = np.ascontiguousarray(fps, np.uint8)
+        addrs = np.ascontiguousarray(addrs, np.uint64)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        n = int(lens.size)
+        assert fps.size == 16 * n and addrs.size == n
+        with self._lock:
+            self._drop(self._b.admit(lane, epoch))
+            m = self._maps.get((lane, epoch))
+            if m is None:
+                h = self._h.skyhost_map_new(14)
+                if not h:
+                    raise MemoryError("skyhost_map_new")
+                m = self._maps[(lane, epoch)] = [h, []]
+                self._segs[(lane, epoch)] = {}               # (epochs_held / cleanup walk this dictionary's keys)
+            new_bytes = C.c_uint64(0)
+            if n:
+                if self._h.skyhost_map_put(m[0], n, fps.ctypes.data, addrs.ctypes.data, lens.ctypes.data, C.byref(new_bytes)) < 0:
+                    raise MemoryError("skyhost_map_put")
+            m[1].append(keep)
+            self._b.nbytes[(lane, epoch)] += int(new_bytes.value)
+            self._drop(self._b.over_budget((lane, epoch)))
+
+    def get_arrays(self, lane: int, epoch: int, fps: np.ndarray):
+        """(addrs [m] uint64, lens [m] uint32, misses, keep): address 0 = not there (yet).  `keep` holds the group's buffers: the caller keeps it until the
+        device has READ the addresses -- another lane may move the group's lane on (or run into the byte budget) meanwhile, and a group that is dropped
+        frees its device memory with its last reference (GPU call r5t: a memory access fault at 1024 chunks, where epochs do get retired)."""
+        fps = np.ascontiguousarray(fps, np.uint8)
+        m_ = fps.size // 16
+        addrs, lens = np.zeros(m_, np.uint64), np.zeros(m_, np.uint32)
+        keep = []
+        with self._lock:
+            m = self._maps.get((lane, epoch))
+            if m is None:
+                miss = m_
+            else:
+                self._b.touch((lane, epoch))
+                miss = int(self._h.skyhost_map_get(m[0], m_, fps.ctypes.data, addrs.ctypes.data, lens.ctypes.data)) if m_ else 0
+                keep = list(m[1])
+            self._b.check_not_evicted(lane, epoch, missing=miss > 0)
+        return addrs, lens, miss, keep
+
+    def cleanup(self):
+        with self._lock:
+            self._drop(list(self._maps))
 
 
 class FileSegmentStore:

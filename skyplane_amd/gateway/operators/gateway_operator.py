@@ -72,6 +72,33 @@ class GatewayOperator(ABC):
             p.join()
         self.processes = []
 
+    def _process_in_lane(self, batch, worker_id):
+        """process_batch as the lane loop calls it.  On the dedup path (ONE lane per worker: the fingerprint table belongs to a context) the work that
+        follows the device call -- recipe headers, payload and side-car files, completion records: ~100 ms of Python and file I/O per 64 chunks -- goes
+        to a helper thread, and the lane reads and launches the next batch meanwhile (round 5; process_batch's `defer`)."""
+        if not (self.dedup_wire and self.async_publish):
+            return self.process_batch(batch)
+        pool = getattr(self._tls, "publish_pool", None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = self._tls.publish_pool = ThreadPoolExecutor(1, thread_name_prefix=f"{self.handle}-publish")
+
+        def defer(fn):
+            def run():
+                try:
+                    for cr, meta in zip(batch, fn()):
+                        self.chunk_store.log_chunk_state(cr, ChunkState.complete, operator_handle=self.handle, worker_id=worker_id, metadata=meta)
+                        if self.output_queue is not None:
+                            self.output_queue.put(cr)
+                except Exception:
+                    self.error_queue.put(traceback.format_exc())
+                    self.error_event.set()
+                    raise
+            return pool.submit(run)
+
+        return self.process_batch(batch, defer=defer)
+
     def worker_loop(self, worker_id: int, *args):
         self.worker_id = worker_id
         while not self.exit_flags[worker_id].is_set() and not self.error_event.is_set():
@@ -185,6 +212,8 @@ class GatewayHipCompress(GatewayOperator):
         # size every lane's pinned arenas for max_batch chunks of max_chunk_bytes when the lane starts, instead of growing them under the first full
         # batches: pinning fresh host memory runs at a few GB/s, which a transfer of seconds would otherwise pay inside its first batches
         self.prealloc = bool(prealloc)
+        self.async_publish = True              # dedup path: a batch is published by a helper thread while the lane launches the next one (_process_in_lane)
+        self.read_threads = 4                  # threads that copy a batch's chunk files into pinned staging (1 = one after the other, rounds 1-4)
         self._tls = threading.local()
 
     # -- process-local ---------------------------------------------------------------------------------
@@ -267,15 +296,19 @@ class GatewayHipCompress(GatewayOperator):
         arena, pos, datas = None, 0, []
         if pinned:
             arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
+        jobs = []
         for cr, size in zip(chunk_reqs, sizes):
+            jobs.append((cr, size, arena[pos:pos + size] if pinned else None))
+            pos += (size + 255) & ~255
+
+        def read_one(job):
+            cr, size, data = job
             path = self.chunk_store.get_chunk_file_path(cr.chunk.chunk_id)
             with open(path, "rb") as f:
-                if not pinned:
+                if data is None:
                     data = f.read()
                     got = len(data)
                 else:
-                    data = arena[pos:pos + size]
-                    pos += (size + 255) & ~255
                     got, view = 0, memoryview(data)
                     while got < size:
                         k = f.readinto(view[got:])
@@ -285,11 +318,32 @@ class GatewayHipCompress(GatewayOperator):
                     got += len(f.read(1))     # a longer file is as wrong as a shorter one
             # same invariant GatewaySender.process asserts at gateway_operator.py:352
             assert got == size, f"chunk {cr.chunk.chunk_id} has size {got}{'+' if got > size else ''} but should be {size}"
-            datas.append(data)
-        return datas
+            return data
 
-    def process_batch(self, chunk_reqs: List[ChunkRequest]) -> List[bool]:
+        # the page cache -> pinned staging copies of a batch run side by side (readinto releases the GIL): a lane that is alone on its worker -- the
+        # dedup path -- otherwise spends as long reading 64 chunk files one after the other (~100 ms) as the device spends on them
+        if pinned and len(jobs) > 1 and self.read_threads > 1:
+            pool = getattr(self._tls, "read_pool", None)
+            if pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                pool = self._tls.read_pool = ThreadPoolExecutor(self.read_threads, thread_name_prefix=f"{self.handle}-read")
+            return list(pool.map(read_one, jobs))
+        return [read_one(j) for j in jobs]
+
+    def process_batch(self, chunk_reqs: List[ChunkRequest], defer=None) -> Optional[List[bool]]:
+        """defer (the lane loop's, dedup path on a real device only): a callable that takes the batch's finishing work -- recipe encoding, payload and
+        side-car files, completion records -- to a helper thread; the call then returns None as soon as the device is done with the batch, and the lane
+        starts the next one meanwhile.  The staging areas the helper still reads alternate between two sets (it is at most one batch behind)."""
         ctx = self._context()
+        deferred = defer is not None and self.dedup_wire and hasattr(ctx, "dedup_literals") and hasattr(ctx, "pinned_buffer")
+        par = ""
+        if deferred:
+            par = str(getattr(self._tls, "parity", 0))
+            self._tls.parity = 1 - int(par)
+            prev = self._tls.__dict__.setdefault("finishing", {}).pop(par, None)
+            if prev is not None:
+                prev.result()                          # the batch before last has left this set of staging areas
         datas = self._read_chunks(chunk_reqs, ctx)
         # frames that go out as they are (no recipes) are produced straight into arena slots when there are free ones
         writer = self._writer(ctx, max((len(d) for d in datas), default=0)) if (self.handoff == "arena" and not self.dedup_wire) else None
@@ -300,7 +354,7 @@ class GatewayHipCompress(GatewayOperator):
             if hasattr(ctx, "pinned_buffer") and hasattr(ctx, "frame_bound"):
                 bounds = [ctx.frame_bound(len(d)) for d in datas]
                 rest = bounds[len(slots):]
-                out = self._arena(ctx, "out", sum((b + 255) & ~255 for b in rest)) if rest else None
+                out = self._arena(ctx, "out" + par, sum((b + 255) & ~255 for b in rest)) if rest else None
                 views, pos = [writer.arena.slot(s)[:b] for s, b in zip(slots, bounds)], 0
                 for b in rest:
                     views.append(out[pos:pos + b])
@@ -314,10 +368,19 @@ class GatewayHipCompress(GatewayOperator):
             for s in slots:
                 writer.give_back(s)
             raise
-        recipes = self._build_recipes(ctx, datas, results) if self.dedup_wire else None
-        self._last_metadata = []
+        recipes = self._build_recipes(ctx, datas, results, lit_name="lit" + par) if self.dedup_wire else None
+        if deferred:
+            sizes = [len(d) for d in datas]
+            self._tls.finishing[par] = defer(lambda: self._publish(chunk_reqs, sizes, results, recipes, writer, slots))
+            return None
+        self._last_metadata = self._publish(chunk_reqs, [len(d) for d in datas], results, recipes, writer, slots)
+        return [True] * len(chunk_reqs)
+
+    def _publish(self, chunk_reqs, sizes, results, recipes, writer, slots) -> List[dict]:
+        """Payload (pointer file, or file) + side-cars of every chunk of a batch the device is done with; returns the status metadata per chunk."""
+        metas, published = [], 0
         try:
-            for k, (cr, data, res) in enumerate(zip(chunk_reqs, datas, results)):
+            for k, (cr, size, res) in enumerate(zip(chunk_reqs, sizes, results)):
                 cid = cr.chunk.chunk_id
                 payload = recipes[k][0] if recipes is not None else res.frame
                 if k < len(slots):
@@ -326,9 +389,12 @@ class GatewayHipCompress(GatewayOperator):
                 else:
                     tmp = sidecar.compressed_path(self.chunk_store, cid).with_suffix(".tmp")
                     with open(tmp, "wb") as f:
-                        f.write(payload)
+                        if hasattr(payload, "write_to"):
+                            payload.write_to(f)           # a recipe in two pieces: its literal frame goes out from where the device put it
+                        else:
+                            f.write(payload)
                     os.replace(tmp, sidecar.compressed_path(self.chunk_store, cid))   # the sender never sees a partial frame
-                meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": len(data)}
+                meta = {"compressed_size_bytes": len(payload), "uncompressed_size_bytes": size}
                 if recipes is not None:
                     meta["dedup_reference_bytes"] = recipes[k][1]
                 if res.md5 is not None:
@@ -336,20 +402,47 @@ class GatewayHipCompress(GatewayOperator):
                     meta["md5_hex"] = res.md5.hex()
                 if res.cuts is not None:
                     meta["cdc_segments"] = int(len(res.cuts))
-                self._last_metadata.append(meta)
+                metas.append(meta)
         except BaseException:
             for sl in slots[published:]:          # slots taken for this batch and never published would stay busy for ever
                 writer.give_back(sl)
             raise
-        return [True] * len(chunk_reqs)
+        return metas
 
-    def _build_recipes(self, ctx, datas, results):
+    def _build_recipes(self, ctx, datas, results, lit_name: str = "lit"):
         """One (payload, referenced bytes) per chunk of the device call that just returned (its CDC results are still the context's last ones)."""
         st = self._tls.__dict__.setdefault("dedup_state", {"lane": random.getrandbits(64), "epoch": 0, "bytes": 0})
         in_len = np.array([len(d) for d in datas], np.uint64)
         prefix, cuts, fps, first, base = ctx.cdc_results(len(datas), in_len)
         plans, lit_bufs, lit_owner = [], [], []
-        # the literal streams of chunks with duplicates are gathered straight into pinned staging (the second device call then uploads asynchronously)
+        if hasattr(ctx, "dedup_literals") and hasattr(ctx, "pinned_buffer"):
+            # round 5: the literal streams are put together and compressed ON THE DEVICE, from the chunks the call above left resident there -- no gather
+            # on the host, no second upload (rounds 2-4: np.concatenate of every chunk's new segments into pinned staging + a second, LZ4-only call)
+            bounds = [ctx.frame_bound(len(d)) for d in datas]
+            lit_arena = self._arena(ctx, lit_name, sum((b + 255) & ~255 for b in bounds))
+            views, pos = [], 0
+            for b in bounds:
+                views.append(lit_arena[pos:pos + b])
+                pos += (b + 255) & ~255
+            t_lit = time.perf_counter()
+            lit_lens, lit_frames = ctx.dedup_literals([len(d) for d in datas], views)
+            if _OP_TRACE:
+                print(f"[op-trace] {self.handle}: literal streams of {len(datas)} chunks on the device in {1e3 * (time.perf_counter() - t_lit):.1f} ms", file=sys.stderr, flush=True)
+            out = []
+            for i, (data, res) in enumerate(zip(datas, results)):
+                lens, kinds, sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
+                nlit = int(lens[kinds == dedup_wire.KIND_LITERAL].sum())
+                assert nlit == lit_lens[i], f"chunk {i}: device literal stream of {lit_lens[i]} bytes, the segment list says {nlit}"
+                frame = res.frame if nlit == len(data) else (lit_frames[i] if lit_frames[i] is not None else b"")
+                out.append((dedup_wire.encode_recipe_parts(st["lane"], st["epoch"], lens, kinds, fps[sl], frame, nlit), int(len(data) - nlit)))
+            st["bytes"] += int(in_len.sum())
+            if st["bytes"] >= self.dedup_epoch_bytes:
+                ctx.dedup_reset()
+                st["epoch"] += 1
+                st["bytes"] = 0
+            return out
+        # (contexts without the device gather -- emulator, test doubles --) the literal streams of chunks with duplicates are gathered straight into
+        # pinned staging (the second device call then uploads asynchronously)
         lit_arena = self._arena(ctx, "lit", sum((len(d) + 255) & ~255 for d in datas)) if hasattr(ctx, "pinned_buffer") else None
         lit_pos = 0
         for i, (data, res) in enumerate(zip(datas, results)):
@@ -461,7 +554,9 @@ class GatewayHipCompress(GatewayOperator):
                     continue
                 for cr in batch:
                     self.chunk_store.log_chunk_state(cr, ChunkState.in_progress, operator_handle=self.handle, worker_id=worker_id)
-                oks = self.process_batch(batch)
+                oks = self._process_in_lane(batch, worker_id)
+                if oks is None:
+                    continue                           # the batch is being published by the lane's helper thread, which also records its completion
                 retry = []
                 for cr, ok, meta in zip(batch, oks, self._last_metadata):
                     if ok:
@@ -479,6 +574,11 @@ class GatewayHipCompress(GatewayOperator):
                 self.error_queue.put(traceback.format_exc())
                 self.error_event.set()
                 self.exit_flags[worker_id].set()
+        for fut in list(getattr(self._tls, "finishing", {}).values()):      # batches still being published by the helper thread
+            try:
+                fut.result()
+            except Exception:
+                pass                                   # (reported by the helper itself)
         for _due, _n, cr in self._parked():           # what still waits goes back to the queue: another worker (or a restart) may finish it
             self.input_queue.put(cr)
         self._parked().clear()
@@ -511,6 +611,14 @@ class GatewayHipCompress(GatewayOperator):
         if ls is not None:
             ls.close()
             self._tls.link_slots = None
+        rp = getattr(self._tls, "read_pool", None)
+        if rp is not None:
+            rp.shutdown(wait=False)
+            self._tls.read_pool = None
+        pp = getattr(self._tls, "publish_pool", None)
+        if pp is not None:
+            pp.shutdown(wait=True)
+            self._tls.publish_pool = None
         if self._ctx is not None:
             self._arenas = {}             # the context frees its pinned blocks
             self._ctx.close()
@@ -555,11 +663,16 @@ class GatewayHipDecompress(GatewayHipCompress):
         self._first_miss = {}
         self._put_done = set()                 # chunk ids whose literal segments are in the store already (a retry must not store them again)
 
-    def _segment_store(self) -> "dedup_wire.SegmentStore":
+    def _process_in_lane(self, batch, worker_id):
+        return self.process_batch(batch)
+
+    def _segment_store(self, on_device: bool = False) -> "dedup_wire.SegmentStore":
         with self._store_lock:
             if self._store is None:
                 if self.dedup_store == "files":
                     self._store = dedup_wire.FileSegmentStore(self.chunk_store.get_chunk_file_path("x").parent / "_segments")
+                elif on_device:
+                    self._store = dedup_wire.DeviceSegmentStore()      # fingerprint -> device address: the chunks are put together on the device
                 else:
                     self._store = dedup_wire.SegmentStore()
             return self._store
@@ -577,6 +690,52 @@ class GatewayHipDecompress(GatewayHipCompress):
         if isinstance(h, str):
             return bytes.fromhex(h)
         return bytes(h)
+
+    def _rebuild_runs(self, cid: str, rec: "dedup_wire.Recipe", lit):
+        """Device variant of _rebuild: (run addresses, run lengths, what must stay alive until the device has read them) -- DEVICE addresses of the byte runs
+        that make up the chunk, neighbours merged -- or None
+        while a referenced segment has not arrived.  lit = the chunk's decoded literal stream as a hip_ops.DeviceBuffer (None when it has none); the store
+        (dedup_wire.DeviceSegmentStore) maps fingerprints to addresses inside such buffers: a later chunk's reference is a piece of an earlier chunk's
+        stream, still where it was decoded.  Whole arrays in and out: no per-segment Python."""
+        store = self._segment_store(on_device=True)
+        segs = rec.segs
+        nseg = len(segs)
+        if not nseg:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint32), None
+        lens = segs["len"].astype(np.uint64)
+        is_lit = segs["kind"] == dedup_wire.KIND_LITERAL
+        llen = np.where(is_lit, lens, 0).astype(np.uint64)
+        lit_start = np.cumsum(llen) - llen
+        fp = np.ascontiguousarray(segs["fp"]).reshape(nseg, 16)
+        li, ri = np.nonzero(is_lit)[0], np.nonzero(~is_lit)[0]
+        src = np.zeros(nseg, np.uint64)
+        keep = []
+        if len(li):
+            src[li] = np.uint64(lit.dptr) + lit_start[li]
+            if cid not in self._put_done:
+                store.put_arrays(rec.lane, rec.epoch, fp[li], src[li], lens[li].astype(np.uint32), lit)
+                self._put_done.add(cid)
+        if len(ri):
+            addrs, hl, miss, keep = store.get_arrays(rec.lane, rec.epoch, fp[ri])
+            if miss:
+                t0 = self._first_miss.setdefault(cid, time.monotonic())
+                if time.monotonic() - t0 > self.dedup_wait_s:
+                    self._put_done.discard(cid)
+                    k = int(ri[np.nonzero(addrs == 0)[0][0]])
+                    raise ValueError(f"[Gateway] chunk {cid}: segment {fp[k].tobytes().hex()} of lane {rec.lane:#x} epoch {rec.epoch} did not arrive "
+                                     f"within {self.dedup_wait_s:.0f} s (is gpu_decompress running with more than one worker process?)")
+                return None
+            bad = np.nonzero(hl.astype(np.uint64) != lens[ri])[0]
+            if len(bad):
+                k = int(ri[bad[0]])
+                raise ValueError(f"[Gateway] chunk {cid}: referenced segment {fp[k].tobytes().hex()} has {int(hl[bad[0]])} bytes, the recipe says {int(lens[k])}")
+            src[ri] = addrs
+        self._first_miss.pop(cid, None)
+        self._put_done.discard(cid)
+        # neighbours in the chunk that are neighbours in memory are one run (a chunk's literals between two references; a run of references into one earlier stream)
+        first = np.concatenate([[True], src[1:] != src[:-1] + lens[:-1]])
+        starts = np.nonzero(first)[0]
+        return src[starts], np.add.reduceat(lens, starts).astype(np.uint32), (lit, keep)      # (a run cannot exceed 32 bits: a chunk cannot -- max_chunk_bytes <= 1 GiB)
 
     def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream.  Runs of literal
@@ -742,6 +901,21 @@ class GatewayHipDecompress(GatewayHipCompress):
         datas, digests = [np.zeros(0, np.uint8)] * len(todo), [None] * len(todo)
         if trace:
             trace.append(time.perf_counter())
+        # Round 5: with a real device behind the context (and the in-process segment store) a recipe's literal stream is decoded into DEVICE memory and stays
+        # there -- the store keeps device buffers --, and the chunk is put together on the device from runs of this and earlier streams, digested there and
+        # copied out once (skyhip_decompress_to_device / skyhip_gather_md5).  Rounds 2-4: literal stream to the host, numpy copies, chunk uploaded again.
+        on_device = hasattr(ctx, "gather_md5") and hasattr(ctx, "decompress_to_device") and self.dedup_store == "memory" and any(r is not None for r in recipes)
+        if on_device:
+            dec_dev = [j for j in dec if recipes[j] is not None]
+            dec = [j for j in dec if recipes[j] is None]
+            if "into" in kwargs:
+                kwargs["into"] = [into[j] for j in dec]
+            if dec_dev:
+                for j, buf in zip(dec_dev, ctx.decompress_to_device([frames[j] for j in dec_dev], [raw_lens[j] for j in dec_dev])):
+                    datas[j] = buf
+            for j in range(len(todo)):
+                if recipes[j] is not None and j not in cached and not recipes[j].lit_raw_len:
+                    datas[j] = None                    # (nothing but references)
         if dec:
             res = ctx.decompress_batch([frames[j] for j in dec], [raw_lens[j] for j in dec], **kwargs)
             dd, gg = res if want_dec else (res, [None] * len(dec))
@@ -757,8 +931,42 @@ class GatewayHipDecompress(GatewayHipCompress):
         n_rec_bytes = sum((recipes[j].raw_len + 255) & ~255 for j in range(len(todo)) if recipes[j] is not None)
         reb_arena = self._arena(ctx, "rebuilt", n_rec_bytes) if (pinned and n_rec_bytes) else None
         reb_pos = 0
+        if on_device:
+            gj, g_src, g_len, g_into, g_keep = [], [], [], [], []
+            for j, rec in enumerate(recipes):
+                if rec is None:
+                    continue
+                lit = datas[j]
+                if (0 if lit is None else len(lit)) != rec.lit_raw_len:
+                    raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {0 if lit is None else len(lit)} bytes, the recipe says {rec.lit_raw_len}")
+                cid_j = chunk_reqs[todo[j]].chunk.chunk_id
+                try:
+                    runs = self._rebuild_runs(cid_j, rec, lit)
+                except BaseException:
+                    cache.pop(cid_j, None)
+                    raise
+                if runs is None:
+                    ready[j] = False
+                    if cid_j not in cache and len(cache) < 4 * self.max_batch:
+                        cache[cid_j] = lit             # (a device buffer: it stays where it is)
+                    continue
+                cache.pop(cid_j, None)
+                if j in slot_of:
+                    dstv = link.views[slot_of[j]]
+                else:
+                    dstv = reb_arena[reb_pos:reb_pos + rec.raw_len]
+                    reb_pos += (rec.raw_len + 255) & ~255
+                gj.append(j); g_src.append(runs[0]); g_len.append(runs[1]); g_into.append(dstv); g_keep.append(runs[2])
+            if gj:
+                outs, digs = ctx.gather_md5(g_src, g_len, g_into, want_md5=bool(want))
+                g_keep.clear()                         # the device has read every run: the buffers may go when their groups do
+                for k, j in enumerate(gj):
+                    datas[j], digests[j] = outs[k], (digs[k] if digs is not None else None)
+            recipes_done = True
+        else:
+            recipes_done = False
         for j, rec in enumerate(recipes):
-            if rec is None:
+            if rec is None or recipes_done:
                 continue
             if len(datas[j]) != rec.lit_raw_len:
                 raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {len(datas[j])} bytes, the recipe says {rec.lit_raw_len}")

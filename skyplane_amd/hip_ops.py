@@ -11,6 +11,7 @@ There is no CPU fallback: construction raises if the extension or the GPU is mis
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -34,6 +35,45 @@ class ChunkResult:
     cuts: Optional[np.ndarray] = None  # CDC END offsets (uint32), last == len(raw)
 
 
+class _DeviceBlock:
+    """Device memory owned from Python (skyhip_dev_alloc): freed when the last DeviceBuffer cut from it goes, or when its context is closed."""
+
+    def __init__(self, ctx: "SkyHipContext", nbytes: int):
+        p = C.c_void_p()
+        ctx._check(ctx._lib.skyhip_dev_alloc(ctx._h, int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes, self._ctx = int(p.value), int(nbytes), ctx
+        ctx._dev_blocks.add(self)
+
+    def free(self):
+        ctx, self._ctx = self._ctx, None
+        if ctx is not None and self.ptr and ctx._h:
+            ctx._lib.skyhip_dev_free(ctx._h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """`nbytes` bytes of device memory at `dptr` (a piece of a block it keeps alive): what the destination's segment store holds instead of bytes when the
+    chunks are put together on the device."""
+
+    __slots__ = ("block", "off", "nbytes")
+
+    def __init__(self, block: _DeviceBlock, off: int, nbytes: int):
+        self.block, self.off, self.nbytes = block, int(off), int(nbytes)
+
+    @property
+    def dptr(self) -> int:
+        return self.block.ptr + self.off
+
+    def __len__(self) -> int:
+        return self.nbytes
+
+
 class SkyHipContext:
     """One per worker process, created AFTER fork (HIP must never be initialised in the daemon parent)."""
 
@@ -45,11 +85,14 @@ class SkyHipContext:
             raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode())
         self._h = h
         self._pinned = {}
+        self._dev_blocks = weakref.WeakSet()      # device memory handed to Python (decompress_to_device): freed with the context at the latest
         self.device_id, self.max_chunk_bytes, self.max_batch = device_id, max_chunk_bytes, max_batch
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
+            for b in list(self._dev_blocks):
+                b.free()
             self._pinned.clear()            # skyhip_destroy frees every block still alive
             self._lib.skyhip_destroy(self._h)
             self._h = None
@@ -142,6 +185,21 @@ class SkyHipContext:
                                    cuts=cuts[i][: n_cuts[i]].copy() if flags & F_CDC else None))
         return res
 
+    def dedup_literals(self, in_lens: Sequence[int], frames_into: Sequence[np.ndarray]):
+        """Dedup on the wire, source side: right after ``process_batch(chunks, flags=F_LZ4 | ... | F_CDC | F_DEDUP)`` over the same chunks, the LZ4 frame
+        of every chunk's literal stream (its new segments back to back), put together and compressed on the device from the chunks still resident there
+        (skyhip_dedup_literals).  frames_into[i]: uint8 array of >= frame_bound(in_lens[i]) bytes, ideally pinned.  Returns (lit_lens, frames): frames[i]
+        is a view of frames_into[i], or None where the chunk has no duplicates (the first call's frame is its literal stream) or no new segment."""
+        n = len(in_lens)
+        outs = list(frames_into)
+        assert len(outs) == n and all(isinstance(o, np.ndarray) and o.dtype == np.uint8 for o in outs)
+        out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        out_cap = (C.c_size_t * n)(*[o.size for o in outs])
+        out_len = (C.c_size_t * n)()
+        lit_len = (C.c_size_t * n)()
+        self._check(self._lib.skyhip_dedup_literals(self._h, n, out_ptrs, out_cap, out_len, lit_len))
+        return [int(x) for x in lit_len], [outs[i][: out_len[i]] if out_len[i] else None for i in range(n)]
+
     # -- device-resident path (bench / kernel-only measurements; pointers are raw device addresses) ----
     def process_device(self, d_in: int, in_off: np.ndarray, in_len: np.ndarray, d_out: int, out_off: np.ndarray, out_cap: np.ndarray,
                        flags: int = F_LZ4 | F_MD5, want_md5: bool = True):
@@ -184,6 +242,47 @@ class SkyHipContext:
         self._check(rc)
         res = [outs[i][: out_len[i]] if into is not None else outs[i][: out_len[i]].tobytes() for i in range(n)]
         return (res, [md5[i].tobytes() for i in range(n)]) if want_md5 else res
+
+    # -- dedup on the wire, destination side: literal streams that stay on the device (gateway/dedup_wire.py) ----
+    def decompress_to_device(self, frames: Sequence, raw_lens: Sequence[int]) -> List["DeviceBuffer"]:
+        """Decode frames[i] (host memory) into device memory that this call allocates -- ONE block for the batch -- and return a DeviceBuffer per frame.
+        Nothing is copied back; the block is freed when the last DeviceBuffer cut from it is garbage-collected (or the context is closed)."""
+        n = len(frames)
+        if n == 0:
+            return []
+        arrs = [np.frombuffer(f, np.uint8) if not isinstance(f, np.ndarray) else np.ascontiguousarray(f.reshape(-1).view(np.uint8)) for f in frames]
+        offs, tot = [], 0
+        for r in raw_lens:
+            offs.append(tot)
+            tot += (int(r) + 255) & ~255
+        block = _DeviceBlock(self, max(tot, 256))
+        in_ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        in_len = (C.c_size_t * n)(*[a.size for a in arrs])
+        dst = (C.c_void_p * n)(*[block.ptr + o for o in offs])
+        out_cap = (C.c_size_t * n)(*[int(r) for r in raw_lens])
+        out_len = (C.c_size_t * n)()
+        status = (C.c_int32 * n)()
+        rc = self._lib.skyhip_decompress_to_device(self._h, n, in_ptrs, in_len, dst, out_cap, out_len, status)
+        self.last_decode_status = list(status)
+        self._check(rc)
+        return [DeviceBuffer(block, o, int(out_len[i])) for i, o in enumerate(offs)]
+
+    def gather_md5(self, run_src: Sequence[np.ndarray], run_len: Sequence[np.ndarray], into: Sequence[np.ndarray], want_md5: bool = True):
+        """Chunk i := the byte runs (DEVICE address run_src[i][k], run_len[i][k] bytes) back to back, put together on the device, copied into into[i]
+        (ideally pinned) and digested there.  Returns (views of into, digests or None)."""
+        n = len(into)
+        assert len(run_src) == n and len(run_len) == n
+        prefix = np.zeros(n + 1, np.uint64)
+        prefix[1:] = np.cumsum([len(x) for x in run_len])
+        src = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint64) for x in run_src]) if n else np.zeros(0, np.uint64), np.uint64)
+        ln = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in run_len]) if n else np.zeros(0, np.uint32), np.uint32)
+        out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in into])
+        out_cap = (C.c_size_t * n)(*[o.size for o in into])
+        out_len = (C.c_size_t * n)()
+        md5 = np.zeros((n, 16), np.uint8) if want_md5 else None
+        self._check(self._lib.skyhip_gather_md5(self._h, n, prefix.ctypes.data, src.ctypes.data if src.size else None, ln.ctypes.data if ln.size else None,
+                                                out_ptrs, out_cap, out_len, md5.ctypes.data if md5 is not None else None))
+        return [into[i][: out_len[i]] for i in range(n)], ([md5[i].tobytes() for i in range(n)] if want_md5 else None)
 
     def decompress_device(self, d_in: int, in_off, in_len, d_out: int, out_off, out_cap):
         n = int(len(in_off))

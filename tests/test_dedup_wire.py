@@ -339,6 +339,73 @@ def test_staging_branches_with_plain_frames_recipes_and_both_in_one_batch(tmp_pa
     assert all("md5_hex" in m for m in dec._last_metadata)
 
 
+class _HostBuf:
+    """hip_ops.DeviceBuffer's surface over host memory: the "device address" is the array's address."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    @property
+    def dptr(self):
+        return self.arr.ctypes.data
+
+    def __len__(self):
+        return self.arr.size
+
+
+class DeviceStoreEmuContext(ArenaEmuDedupContext):
+    """+ the calls that let gpu_decompress put a recipe's chunk together ON THE DEVICE (skyhip_decompress_to_device / skyhip_gather_md5), here over host
+    memory: literal streams stay where they were decoded, the segment store holds buffers with an address, chunks are gathered from byte runs."""
+
+    def __init__(self):
+        super().__init__()
+        self.gathers = 0
+
+    def decompress_to_device(self, frames, raw_lens):
+        return [_HostBuf(np.frombuffer(o, np.uint8).copy()) for o in ArenaEmuDedupContext.decompress_batch(self, frames, raw_lens)]
+
+    def gather_md5(self, run_src, run_len, into, want_md5=True):
+        import ctypes
+
+        outs, digs = [], []
+        for src, ln, dst in zip(run_src, run_len, into):
+            blob = b"".join(ctypes.string_at(int(a), int(n)) for a, n in zip(src, ln))
+            dst[:len(blob)] = np.frombuffer(blob, np.uint8)
+            outs.append(dst[:len(blob)])
+            digs.append(hashlib.md5(blob).digest())
+        self.gathers += 1
+        return outs, (digs if want_md5 else None)
+
+
+def test_recipes_are_put_together_from_device_resident_runs(tmp_path):
+    """The destination's device path (round 5): literal streams decoded to "device" memory and kept there by the segment store, chunks gathered from runs
+    of this and earlier streams, plain frames in the same batch decoded as before, a reference before its literal waits (its stream stays put), and the
+    decoded chunks land in slot files published as hard links."""
+    chunks = _dup_chunks(n=6, size=512 << 10)
+    src, dst, reqs = _stores(tmp_path, chunks)
+    dctx = DeviceStoreEmuContext()
+    comp, dec = _ops(src, dst, ArenaEmuDedupContext(), dctx)
+    plain = GatewayHipCompress("gpu_compress_1", "local:t", GatewayQueue(), GatewayQueue(), Event(), Queue(), src, n_processes=1, max_batch=8,
+                               max_chunk_bytes=4 << 20, device_ids=[0], context_factory=lambda d, mc, mb: ArenaEmuDedupContext())
+    assert all(plain.process_batch(reqs[:1]))            # one chunk as a plain frame ...
+    assert all(comp.process_batch(reqs[1:]))             # ... five as recipes
+    _ship(src, dst, reqs)
+    oks = dec.process_batch(reqs[4:])                    # the last two first: what they reference in chunks 1-3 has not arrived
+    assert not all(oks)
+    waiting = [cr for cr, ok in zip(reqs[4:], oks) if not ok]
+    assert all(dec.process_batch(reqs[:4]))              # plain + recipes in one batch
+    assert all(dec.process_batch(waiting))
+    assert dctx.gathers >= 2
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+    store = dec._segment_store()
+    assert isinstance(store, dedup_wire.DeviceSegmentStore) and store._maps       # fingerprint -> address, in csrc/skyhost.c's map
+    assert all(isinstance(b, _HostBuf) for m in store._maps.values() for b in m[1]) and store.bytes_held > 0      # ... and the buffers the addresses point into
+    slot_inodes = {f.stat().st_ino for f in (tmp_path / "dst").glob("_outslot_*")}
+    assert slot_inodes and any(dst.get_chunk_file_path(cr.chunk.chunk_id).stat().st_ino in slot_inodes for cr in reqs)
+    dec.worker_exit(0)
+
+
 def test_file_segment_store_is_shared_between_processes(tmp_path):
     import multiprocessing as mp
 
@@ -544,3 +611,105 @@ def test_not_ready_chunks_wait_with_backoff_inside_the_lane(tmp_path):
     assert dec._take_batch() == [] and len(dec._parked()) == 1             # not due yet: stays parked, the loop does not spin on it
     time.sleep(0.02)
     assert [c.chunk.chunk_id for c in dec._take_batch()] == [reqs[1].chunk.chunk_id] and not dec._parked()
+
+
+def test_native_fingerprint_map_and_device_store_bounds():
+    """csrc/skyhost.c through DeviceSegmentStore: whole-array put / get, first value wins, the map grows, misses are counted; a lane moving on drops the
+    old epoch's map together with the buffers it kept alive (= the device memory they own), like SegmentStore drops its dictionaries."""
+    import gc
+    import weakref
+
+    class Buf:
+        pass
+
+    rng = np.random.default_rng(5)
+    st = dedup_wire.DeviceSegmentStore(keep_epochs=2, max_bytes=1 << 40)
+    n = 50_000                                               # (more than the map's first 16384 slots: it grows twice)
+    fps = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    addrs = rng.integers(1, 1 << 48, n, dtype=np.uint64)
+    lens = rng.integers(1, 16385, n, dtype=np.uint32)
+    b0 = Buf()
+    st.put_arrays(7, 0, fps, addrs, lens, b0)
+    assert st.bytes_held == int(lens.sum())
+    a, l, miss, keep = st.get_arrays(7, 0, fps[::3])
+    assert len(keep) == 1
+    assert miss == 0 and (a == addrs[::3]).all() and (l == lens[::3]).all()
+    st.put_arrays(7, 0, fps[:10], addrs[:10] + np.uint64(5), lens[:10], Buf())      # the same fingerprints again: the first value stays
+    a, l, miss, _ = st.get_arrays(7, 0, fps[:10])
+    assert (a == addrs[:10]).all() and st.bytes_held == int(lens.sum())
+    other = rng.integers(0, 256, (5, 16), dtype=np.uint8)
+    a, l, miss, _ = st.get_arrays(7, 0, np.concatenate([other, fps[:2]]))
+    assert miss == 5 and (a[:5] == 0).all() and (a[5:] == addrs[:2]).all()
+    assert st.get_arrays(7, 1, fps[:4])[2] == 4 and st.get_arrays(8, 0, fps[:4])[2] == 4      # another epoch / lane: nothing
+    ref0 = weakref.ref(b0)
+    del b0, keep, _                                          # (a look-up's `keep` is what holds a group's buffers while the device reads them)
+    st.put_arrays(7, 1, fps[:1], addrs[:1], lens[:1], Buf())
+    assert st.epochs_held(7) == [0, 1] and ref0() is not None
+    st.put_arrays(7, 2, fps[:1], addrs[:1], lens[:1], Buf())                          # epoch 0 is older than keep_epochs now
+    gc.collect()
+    assert st.epochs_held(7) == [1, 2] and ref0() is None and st.get_arrays(7, 0, fps[:4])[2] == 4
+    st.cleanup()
+    assert st.bytes_held == 0 and not st._maps
+
+
+class DeviceSourceEmuContext(ArenaEmuDedupContext):
+    """+ skyhip_dedup_literals' call shape on the host: the literal streams of the call just made, compressed into the caller's views."""
+
+    def process_batch(self, chunks, flags=3, frames_into=None):
+        if flags & 4:
+            self._raw = [bytes(c) for c in chunks]
+        return super().process_batch(chunks, flags=flags, frames_into=frames_into)
+
+    def dedup_literals(self, in_lens, frames_into):
+        prefix, cuts, fps, first, base = self.last
+        lit_lens, frames = [], []
+        for i, (raw, view) in enumerate(zip(self._raw, frames_into)):
+            lens, kinds, _sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
+            ends = np.cumsum(lens.astype(np.int64))
+            lit = b"".join(raw[e - l:e] for e, l, k in zip(ends, lens, kinds) if k == dedup_wire.KIND_LITERAL)
+            lit_lens.append(len(lit))
+            if len(lit) in (0, len(raw)):
+                frames.append(None)
+                continue
+            f = np.frombuffer(emulib.process([lit], flags=1)[0][0], np.uint8)
+            view[:f.size] = f
+            frames.append(view[:f.size])
+        return lit_lens, frames
+
+
+def test_source_lane_publishes_a_batch_while_the_next_one_is_on_the_device(tmp_path):
+    """Round 5, source side of the dedup path: literal streams from the device call (dedup_literals), recipes written in two pieces (RecipeParts), and the
+    lane's helper thread publishing batch k -- payload files, side-cars, completion records, output queue -- while batch k + 1 is read and launched; the
+    staging areas alternate between two sets.  What arrives at the destination is byte for byte what the synchronous path produces."""
+    chunks = _dup_chunks(n=9, size=256 << 10)
+    src, dst, reqs = _stores(tmp_path, chunks)
+    comp, dec = _ops(src, dst, DeviceSourceEmuContext(), ArenaEmuDedupContext())
+    comp.worker_id = 0
+    q_out = comp.output_queue
+    for k in (0, 3, 6):                                   # three batches: the third one waits for the first to have left its staging set
+        assert comp._process_in_lane(reqs[k:k + 3], 0) is None
+    for fut in list(comp._tls.finishing.values()):
+        fut.result(timeout=30)
+    got = []
+    while not q_out.q.empty():
+        got.append(q_out.q.get().chunk.chunk_id)
+    assert got == [cr.chunk.chunk_id for cr in reqs]          # completed in order, by the helper
+    assert {"out0", "out1", "lit0", "lit1"} <= set(comp._arenas)
+    payloads = [sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes() for cr in reqs]
+    assert all(dedup_wire.is_recipe(p) for p in payloads)
+    # the same stream through the synchronous path of a fresh operator: identical recipes
+    src2, _dst2, reqs2 = _stores(tmp_path / "sync", chunks)
+    comp2, _ = _ops(src2, _dst2, ArenaEmuDedupContext(), ArenaEmuDedupContext())
+    comp2._tls.dedup_state = dict(comp._tls.dedup_state, epoch=0, bytes=0)        # same lane id in the recipe headers
+    for k in (0, 3, 6):
+        assert all(comp2.process_batch(reqs2[k:k + 3]))
+    assert payloads == [sidecar.compressed_path(src2, cr.chunk.chunk_id).read_bytes() for cr in reqs2]
+    _ship(src, dst, reqs)
+    assert all(dec.process_batch(reqs))
+    for cr, c in zip(reqs, chunks):
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+    recs = []
+    while not src.chunk_status_queue.empty():
+        recs.append(src.chunk_status_queue.get())
+    assert sum(r["state"] == "complete" for r in recs) == 9
+    comp.worker_exit(0)

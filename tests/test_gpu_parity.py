@@ -418,3 +418,42 @@ def test_dedup_wire_operators_roundtrip_on_gpu(ctx, tmp_path):
     for cr, c in zip(reqs, chunks):
         assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
 
+
+
+def test_dedup_literal_streams_are_put_together_on_the_device(ctx):
+    """skyhip_dedup_literals (round 5: dedup on the wire without a host gather): for every chunk of the CDC + DEDUP call just made, the LZ4 frame of its NEW
+    segments back to back, built from the chunks still resident on the device, decodes (liblz4) to exactly what numpy gathers from the host copy with the
+    same cuts and first-seen indices; chunks without duplicates and chunks without new segments get no second frame."""
+    from skyplane_amd import hip_ops
+    from skyplane_amd.gateway import dedup_wire
+    from tests import test_dedup_wire as T
+
+    chunks = T._dup_chunks(n=4, size=1 << 20)
+    chunks[2] = chunks[0]                                  # a chunk that is nothing but references
+    chunks.append(synth.gen_random(synth.rng_for(5), 300_001).tobytes())      # ... and one without any duplicate (ragged length)
+    ctx.dedup_reset()
+    res = ctx.process_batch(chunks[:4], flags=hip_ops.F_LZ4 | hip_ops.F_MD5 | hip_ops.F_CDC | hip_ops.F_DEDUP)
+    for rnd, batch in enumerate((chunks[:4], chunks[1:5])):
+        if rnd:
+            res = ctx.process_batch(batch, flags=hip_ops.F_LZ4 | hip_ops.F_MD5 | hip_ops.F_CDC | hip_ops.F_DEDUP)
+        lens_in = np.array([len(c) for c in batch], np.uint64)
+        prefix, cuts, fps, first, base = ctx.cdc_results(len(batch), lens_in)
+        views = [np.empty(hip_ops.frame_bound(len(c)), np.uint8) for c in batch]
+        lit_lens, frames = ctx.dedup_literals([len(c) for c in batch], views)
+        seen_none = seen_frame = 0
+        for i, c in enumerate(batch):
+            lens, kinds, _sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
+            ends = np.cumsum(lens.astype(np.int64))
+            want = b"".join(c[e - l:e] for e, l, k in zip(ends, lens, kinds) if k == dedup_wire.KIND_LITERAL)
+            assert lit_lens[i] == len(want), (rnd, i)
+            if len(want) in (0, len(c)):
+                assert frames[i] is None, (rnd, i)
+                seen_none += 1
+            else:
+                assert ref.lz4f_decompress(frames[i].tobytes(), len(want)) == want, (rnd, i)
+                seen_frame += 1
+        assert seen_none and (seen_frame or rnd == 1), (rnd, seen_none, seen_frame)      # (round 1: every chunk but the random one was seen whole in round 0)
+    # the call is only valid right after its CDC + DEDUP batch
+    ctx.process_batch(chunks[:2], flags=hip_ops.F_LZ4)
+    with pytest.raises(Exception):
+        ctx.dedup_literals([len(c) for c in chunks[:2]], [np.empty(hip_ops.frame_bound(len(c)), np.uint8) for c in chunks[:2]])
