@@ -144,6 +144,8 @@ def main():
                     "one in eight -- the destination operator has compared every chunk's device-side digest with the sender's already) and DELETED as it "
                     "arrives, which is what frees the destination's page-locked slot files (shm_arena.LinkSlots) for the next chunks")
     ap.add_argument("--out-slots", type=int, default=-1, help="slot files per destination lane (-1 = the operator's default, 0 = plain writes)")
+    ap.add_argument("--dedup-epoch-mb", type=int, default=2048, help="--dedup-wire: the source starts a new table epoch after this many MB (the planner patch's default, INTEGRATION 10)")
+    ap.add_argument("--dst-fill-wait-ms", type=float, default=-1, help="destination lanes collect for up to this long before a device call (-1 = the operator's default)")
     ap.add_argument("--dst-depth", type=int, default=0, help="pipeline lanes per destination worker (0 = the operator's default)")
     ap.add_argument("--src-depth", type=int, default=0, help="pipeline lanes per source worker (0 = the operator's default)")
     a = ap.parse_args()
@@ -204,10 +206,11 @@ def main():
         kw = {"context_factory": factory} if factory else {}
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
-                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, pipeline_depth=a.src_depth or None, **kw)
+                                max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, pipeline_depth=a.src_depth or None,
+                                dedup_epoch_bytes=a.dedup_epoch_mb << 20, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
                                    max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None,
-                                   out_slots=None if a.out_slots < 0 else a.out_slots, **kw)
+                                   out_slots=None if a.out_slots < 0 else a.out_slots, fill_wait_s=None if a.dst_fill_wait_ms < 0 else a.dst_fill_wait_ms / 1e3, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
         go = threading.Event()

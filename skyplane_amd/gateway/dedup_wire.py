@@ -299,8 +299,11 @@ class DeviceSegmentStore(SegmentStore):
     lock the destination's lanes share).  Same bounds as SegmentStore (epochs kept per lane, byte budget, idle time); a group that goes takes its map
     and the buffers it kept alive (hip_ops.DeviceBuffer: the device memory is freed with the last of them) with it."""
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
+    def __init__(self, keep_epochs: int = 4, max_bytes: int = 32 << 30, **kwargs):
+        # (device memory is what this store spends: 288 GB of it, against the host RAM the other two stores live in.  Four epochs per lane: a source that
+        # publishes batches while the next ones are on the device runs two epochs ahead of a destination that pays a digest chain per batch -- GPU call
+        # r5u: with two epochs kept, chunks of epoch 0 were still queued when epoch 2 retired their literals)
+        super().__init__(keep_epochs=keep_epochs, max_bytes=max_bytes, **kwargs)
         from skyplane_amd import _hostlib
 
         self._h = _hostlib.load()
