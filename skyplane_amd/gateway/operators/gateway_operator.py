@@ -202,9 +202,13 @@ class GatewayHipCompress(GatewayOperator):
         # whole-chunk MD5 is a serial chain of ~0.1 s per 8 MiB whatever the batch size: with one lane the worker would sit
         # in that call while the next batch waits; with several, lane B uploads and compresses while lane A's chain runs (the C ABI is
         # synchronous per context and ctypes releases the GIL, so lanes overlap on the device and in the kernel's file I/O).
-        # Default 3; ONE lane when the source deduplicates on the wire: every lane owns a device context with its own fingerprint table (up to GiBs of
+        # Default 2 (round 5; 3 before): the loopback moves 33.6 / 44.0 / 38.1 Gbit/s with 1 / 2 / 3 lanes per worker (profiles/r5_operator_lanes.txt) -- every
+        # lane's context brings six HIP streams, a process's streams share GPU_MAX_HW_QUEUES (4) hardware queues, and kernels of streams that share a
+        # queue serialise: a third lane mostly queues behind the other two's 80 ms digest launches.  (More hardware queues are no way out: at 24 the same
+        # loopback fell to 17.7 Gbit/s, although the bare device calls of scripts/host_path_bench.py then run three lanes at one lane's rate.)
+        # ONE lane when the source deduplicates on the wire: every lane owns a device context with its own fingerprint table (up to GiBs of
         # HBM each) and duplicates that land on different lanes are never matched, so several lanes cost memory and hit rate.
-        self.pipeline_depth = max(1, int(pipeline_depth)) if pipeline_depth is not None else (1 if self.dedup_wire else 3)
+        self.pipeline_depth = max(1, int(pipeline_depth)) if pipeline_depth is not None else (1 if self.dedup_wire else 2)
         # a lane that finds fewer than max_batch requests keeps collecting for up to this long before it launches: trickling input otherwise turns into
         # many small calls that each pay the full chain latency (~80 ms).  30 ms with three lanes per worker (another lane is on the device meanwhile);
         # 4 ms for the single lane of the dedup path, where a waiting lane is an idle device (profiles/r3_e2e_fill_wait.txt)
