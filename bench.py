@@ -11,8 +11,8 @@ Rank 0 prints ONE JSON line.  After the timed region every digest of the step is
 frame still resident against liblz4 (the reference's decoder), on a pool of CPU processes forked before HIP is
 initialised; the same pool times the reference's CPU path (cpu_baseline: one PROCESS per schedulable core).
 The default 1-GPU run (no workload flags) also carries a `secondary` object: short verified runs of configs[2]
-(`--cdc`) and of the configs[3] stream on one GPU (`--stream mixed --chunks 16384`), each its own process after the
-headline's device memory has been given back, each with the same roofline / verified fields (`--no-secondary` skips them).
+(`--cdc`) and of the configs[3] stream on one GPU (`--stream mixed --chunks 16384`), each its own process BEFORE this one
+touches the GPU, each with the same roofline / verified fields (`--no-secondary` skips them).
 Progress goes to stderr as `[bench +seconds] ...` lines (a heartbeat: the JSON line is the only thing on stdout).
 
 --context emu (tests only): the shipping kernel source under the CPU SIMT emulator, tensors on the host, gloo instead of
@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=1024, help="chunks per LZ4 launch on the block-queue path (device-resident batches below 2 chunks per CU and "
                                                                 "SKYHIP_FRAMES_MIN=0 runs; block scratch = 8.06 MiB per chunk); the default run writes frames in place and never uses it")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] / configs[3]-on-one-GPU runs appended to the default 1-GPU line")
-    ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--secondary-steps", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", choices=["auto", "silesia", "mixed"], default="auto",
                     help="auto = silesia (configs[1]) on one GPU, mixed (configs[3]) on several")
@@ -254,6 +254,17 @@ def main():
     cb = args.chunk_bytes
     stream = args.stream if args.stream != "auto" else ("silesia" if world == 1 else "mixed")
     n_target = args.chunks or (8192 if (stream == "silesia" or args.cdc or world == 1) else 16384)
+
+    # ---- the other single-GPU configurations, in front of whoever runs the default command: each in its own process, BEFORE this process touches the
+    # GPU.  (Round 5's first version ran them after the headline, with this process's HIP runtime still holding its hardware queues: the configs[2] run,
+    # which asks for 16 queues of its own, then took 326 ms per step instead of 151-156 -- GPU call r5y -- : queues of two processes beyond what the
+    # hardware holds are time-sliced, and kernels that are meant to run side by side take turns.)
+    secondary_res = None
+    if rank == 0 and world == 1 and not emu and not args.cdc and args.stream == "auto" and args.chunks == 0 and cb == synth.CHUNK_BYTES and not args.no_secondary:
+        secondary_res = {}
+        for key, extra in (("configs[2]", ["--cdc"]), ("configs[3] stream on one GPU", ["--stream", "mixed", "--chunks", "16384"])):
+            log(f"secondary run {key}: bench.py {' '.join(extra)} --steps {args.secondary_steps}")
+            secondary_res[key] = run_secondary(extra, args.secondary_steps, 1)
 
     # ---- host unit (deterministic), then the CPU pool, then -- and only then -- the HIP runtime ----
     t0 = time.perf_counter()
@@ -583,6 +594,18 @@ def main():
                 per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
                 res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
                 res["roofline"]["traffic_source"] = t["source"]
+                # The STAGE reads the stream more than once: whole-chunk MD5 is a second pass over the same bytes -- it cannot ride the
+                # compressor's LDS copy: a chain consumes its chunk at ~100 MB/s, a workgroup eats a chunk at ~2.3 GB/s --, FETCH 1.0 B per input byte with
+                # no re-reads (profiles/r3_pmc_traffic_kernels.txt); with --cdc the candidates kernel reads it again with a 64-byte warm-up per 512 (x 1.125) and
+                # the segment digests once more.  SURVEY 8d's algorithmic figure (N + C) counts one read.
+                extra = 1.0 + ((1.125 + 1.0) if args.cdc else 0.0)
+                res["roofline"]["stage_traffic"] = {
+                    "bytes_per_input_byte": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"] + extra, 4),
+                    "algorithmic_bytes_per_input_byte": round(1.0 + tm.lz4_out_bytes / max(tm.lz4_in_bytes, 1), 4),
+                    "parts": {"compressor (measured)": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"], 4), "sky_md5_chunks (one read, measured r3)": 1.0,
+                              **({"sky_gear_candidates (512 + 64 bytes per lane)": 1.125, "sky_segment_md5 (one read)": 1.0} if args.cdc else {})},
+                    "note": "the digest(s) and the CDC kernels are separate passes over the resident stream by construction: a serial chain per chunk / per segment "
+                            "cannot share the compressor's one-block-at-a-time LDS copy"}
         if args.cdc:
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
             prefix, cuts, fps, first, base = ctxs[last_lane].cdc_results(n_chunks, in_len)      # (the context that ran the last step)
@@ -618,16 +641,8 @@ def main():
     for c_ in ctxs + md5_ctxs:
         c_.close()
     if rank == 0:
-        default_run = world == 1 and not emu and not args.cdc and args.stream == "auto" and args.chunks == 0 and cb == synth.CHUNK_BYTES
-        if default_run and not args.no_secondary:
-            # the other single-GPU configurations, in front of whoever runs the default command: each in its own process, after this one's
-            # stream and frame slots have gone back to the device
-            del d_in, d_outs, d_out, tile
-            torch.cuda.empty_cache()
-            res["secondary"] = {}
-            for key, extra in (("configs[2]", ["--cdc"]), ("configs[3] stream on one GPU", ["--stream", "mixed", "--chunks", "16384"])):
-                log(f"secondary run {key}: bench.py {' '.join(extra)} --steps {args.secondary_steps}")
-                res["secondary"][key] = run_secondary(extra, args.secondary_steps, 1)
+        if secondary_res is not None:
+            res["secondary"] = secondary_res
         log("done")
         print(json.dumps(res), flush=True)
     if world > 1:
