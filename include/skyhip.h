@@ -159,7 +159,9 @@ int  skyhip_cdc_results(skyhip_ctx* ctx, int n, uint64_t* cut_prefix /* n+1 */, 
 int  skyhip_dedup_literals(skyhip_ctx* ctx, int n, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* lit_len);
 
 /* Dedup on the wire, destination side (skyplane_amd/gateway/dedup_wire.py): a recipe's chunk is put together ON THE DEVICE from literal streams that stay
- * there.  skyhip_dev_alloc / skyhip_dev_free: device memory the caller owns (the segment store's literal streams).  skyhip_decompress_to_device: like
+ * there.  skyhip_dev_alloc / skyhip_dev_free: device memory the caller owns (the segment store's literal streams); it belongs to the PROCESS, not to the
+ * context that allocated it -- any context of the process may read it, it outlives skyhip_destroy, and skyhip_dev_free(NULL, p) frees it when that context
+ * is gone (the lanes of a worker share one store and leave at different times).  skyhip_decompress_to_device: like
  * skyhip_decompress_batch, but frame i is decoded into DEVICE memory dst[i] (>= out_cap[i] bytes) and nothing comes back to the host but lengths and
  * status.  skyhip_gather_md5: chunk i := the runs run_prefix[i] .. run_prefix[i+1] back to back, run k being run_len[k] bytes at DEVICE address
  * run_src[k]; the chunk is copied to host out[i] (pinned memory: asynchronously, beside the digest) and md5[i] (may be NULL) is its digest --

@@ -996,8 +996,8 @@ int skyhip_dev_alloc(skyhip_ctx* c, size_t bytes, void** out) {
     return SKYHIP_OK;
 }
 int skyhip_dev_free(skyhip_ctx* c, void* p) {
-    if (!c) return SKYHIP_E_INVAL;
     if (!p) return SKYHIP_OK;
+    if (!c) return hipFree(p) == hipSuccess ? SKYHIP_OK : SKYHIP_E_HIP;      // (the context that allocated it is gone: device memory belongs to the process, see skyhip.h)
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipFree(p));
     return SKYHIP_OK;

@@ -36,7 +36,7 @@ class ChunkResult:
 
 
 class _DeviceBlock:
-    """Device memory owned from Python (skyhip_dev_alloc): freed when the last DeviceBuffer cut from it goes, or when its context is closed."""
+    """Device memory owned from Python (skyhip_dev_alloc): freed when the last DeviceBuffer cut from it goes -- also after its context was closed."""
 
     def __init__(self, ctx: "SkyHipContext", nbytes: int):
         p = C.c_void_p()
@@ -46,8 +46,8 @@ class _DeviceBlock:
 
     def free(self):
         ctx, self._ctx = self._ctx, None
-        if ctx is not None and self.ptr and ctx._h:
-            ctx._lib.skyhip_dev_free(ctx._h, C.c_void_p(self.ptr))
+        if ctx is not None and self.ptr:
+            ctx._lib.skyhip_dev_free(ctx._h if ctx._h else None, C.c_void_p(self.ptr))      # (the memory is the process's: it may outlive its context)
         self.ptr = 0
 
     def __del__(self):
@@ -85,15 +85,15 @@ class SkyHipContext:
             raise SkyHipError(rc, self._lib.skyhip_strerror(rc).decode())
         self._h = h
         self._pinned = {}
-        self._dev_blocks = weakref.WeakSet()      # device memory handed to Python (decompress_to_device): freed with the context at the latest
+        self._dev_blocks = weakref.WeakSet()      # device memory handed to Python (decompress_to_device): bookkeeping only, it is freed with its last reference
         self.device_id, self.max_chunk_bytes, self.max_batch = device_id, max_chunk_bytes, max_batch
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            for b in list(self._dev_blocks):
-                b.free()
-            self._pinned.clear()            # skyhip_destroy frees every block still alive
+            self._pinned.clear()            # skyhip_destroy frees every pinned block still alive (device blocks handed to Python -- _DeviceBlock -- are the
+                                            # process's: another lane's context may still be reading them through the shared segment store; they go
+                                            # with their last reference)
             self._lib.skyhip_destroy(self._h)
             self._h = None
 

@@ -457,3 +457,40 @@ def test_dedup_literal_streams_are_put_together_on_the_device(ctx):
     ctx.process_batch(chunks[:2], flags=hip_ops.F_LZ4)
     with pytest.raises(Exception):
         ctx.dedup_literals([len(c) for c in chunks[:2]], [np.empty(hip_ops.frame_bound(len(c)), np.uint8) for c in chunks[:2]])
+
+
+def test_device_resident_literal_streams_and_gathered_chunks(ctx):
+    """skyhip_decompress_to_device + skyhip_gather_md5 (dedup on the wire, destination side): frames decoded into device memory that Python owns, chunks put
+    together on the device from byte runs of several such buffers -- any alignment, runs of 1 byte to megabytes, an empty chunk --, digested there and
+    copied out; the memory outlives the context that allocated it and is readable by another context of the process."""
+    from skyplane_amd import hip_ops
+
+    rng = np.random.default_rng(9)
+    streams = [synth.gen_text(synth.rng_for(3, k), n).tobytes() for k, n in enumerate((1 << 20, 70_001, 13, 300_000))]
+    bufs = ctx.decompress_to_device([ref.lz4f_compress(s) for s in streams], [len(s) for s in streams])
+    assert [len(b) for b in bufs] == [len(s) for s in streams]
+    chunks_src, chunks_len, want = [], [], []
+    for _c in range(5):
+        src, ln, blob = [], [], b""
+        for _r in range(int(rng.integers(1, 200))):
+            k = int(rng.integers(0, len(streams)))
+            n = int(min(rng.integers(1, 1 << int(rng.integers(1, 18))), len(streams[k])))
+            o = int(rng.integers(0, len(streams[k]) - n + 1))
+            src.append(bufs[k].dptr + o); ln.append(n); blob += streams[k][o:o + n]
+            if len(blob) > (6 << 20):
+                break
+        chunks_src.append(np.array(src, np.uint64)); chunks_len.append(np.array(ln, np.uint32)); want.append(blob)
+    chunks_src.append(np.zeros(0, np.uint64)); chunks_len.append(np.zeros(0, np.uint32)); want.append(b"")      # an empty chunk
+    into = [np.empty(max(len(w), 1), np.uint8) for w in want]
+    outs, digs = ctx.gather_md5(chunks_src, chunks_len, into)
+    for o, d, w in zip(outs, digs, want):
+        assert o.tobytes() == w and d == hashlib.md5(w).digest()
+    # another context of the process reads the same device memory; the first context's buffers survive ITS closing
+    other = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=4)
+    tmp = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=4)
+    (tb,) = tmp.decompress_to_device([ref.lz4f_compress(streams[1])], [len(streams[1])])
+    tmp.close()
+    outs, digs = other.gather_md5([np.array([tb.dptr, bufs[0].dptr + 5], np.uint64)], [np.array([len(tb), 1000], np.uint32)], [np.empty(len(tb) + 1000, np.uint8)])
+    assert outs[0].tobytes() == streams[1] + streams[0][5:1005] and digs[0] == hashlib.md5(streams[1] + streams[0][5:1005]).digest()
+    del tb, bufs
+    other.close()
