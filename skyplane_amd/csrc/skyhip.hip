@@ -992,11 +992,13 @@ int skyhip_dev_alloc(skyhip_ctx* c, size_t bytes, void** out) {
     if (!c || !out || bytes == 0) return SKYHIP_E_INVAL;
     *out = nullptr;
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipMalloc(out, bytes));
+    if (sky_guard_on()) HIPCHK(c, sky_guard_malloc(out, bytes, true, 256));      // (tests/test_gpu_guard.py: the block ends at an unmapped page)
+    else HIPCHK(c, hipMalloc(out, bytes));
     return SKYHIP_OK;
 }
 int skyhip_dev_free(skyhip_ctx* c, void* p) {
     if (!p) return SKYHIP_OK;
+    if (sky_guard_on()) return sky_guard_free(p) == hipSuccess ? SKYHIP_OK : SKYHIP_E_INVAL;
     if (!c) return hipFree(p) == hipSuccess ? SKYHIP_OK : SKYHIP_E_HIP;      // (the context that allocated it is gone: device memory belongs to the process, see skyhip.h)
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipFree(p));

@@ -5,7 +5,7 @@ against an unmapped page, with no slack) and AMD_SERIALIZE_KERNEL=3: an access o
 GPU node-N", which the parent reports as a failing test.  The caller-owned buffers (d_in / d_out of the device-resident calls) come from
 skyhip_debug_guard_alloc: the last input byte is the last mapped byte, the last byte of the last frame region likewise.  TEST INFRASTRUCTURE ONLY.
 
-usage: python tests/_gpu_guard_run.py {probe_in|probe_over|probe_under|lz4|batch|lz4d|cdc|frames512|smoke}
+usage: python tests/_gpu_guard_run.py {probe_in|probe_over|probe_under|lz4|batch|lz4d|cdc|dedup|frames512|smoke}
 """
 import ctypes as C
 import hashlib
@@ -225,6 +225,49 @@ def run_cdc():
     print(f"OK cdc ({n_cases} cases)")
 
 
+def run_dedup():
+    """dedup on the wire on the device: literal streams put together from the staged chunks (skyhip_dedup_literals), frames decoded into device blocks,
+    chunks gathered from runs that end on a block's last byte (skyhip_decompress_to_device / skyhip_gather_md5) -- staging areas, the literal buffer and
+    the device blocks all end at an unmapped page"""
+    from skyplane_amd import hip_ops, synth
+    from skyplane_amd.gateway import dedup_wire
+
+    n_cases = 0
+    with _ctx(max_chunk=1 << 20, max_batch=4) as ctx:
+        for size in (1 << 20, 300_001, 70_000):
+            stream = synth.dedup_stream(4 * size, dup_fraction=0.5, config_id=3)
+            chunks = [stream[i * size:(i + 1) * size].tobytes() for i in range(4)]
+            chunks[3] = chunks[3][: size - 13]
+            ctx.dedup_reset()
+            ctx.process_batch(chunks, flags=hip_ops.F_LZ4 | hip_ops.F_MD5 | hip_ops.F_CDC | hip_ops.F_DEDUP)
+            lens_in = np.array([len(c) for c in chunks], np.uint64)
+            prefix, cuts, fps, first, base = ctx.cdc_results(4, lens_in)
+            views = [np.empty(hip_ops.frame_bound(len(c)), np.uint8) for c in chunks]
+            lit_lens, frames = ctx.dedup_literals([len(c) for c in chunks], views)
+            lits = []
+            for i, c in enumerate(chunks):
+                lens, kinds, _sl = dedup_wire.classify_segments(prefix, cuts, first, base, i)
+                ends = np.cumsum(lens.astype(np.int64))
+                want = b"".join(c[e - l:e] for e, l, k in zip(ends, lens, kinds) if k == dedup_wire.KIND_LITERAL)
+                assert lit_lens[i] == len(want)
+                if frames[i] is not None:
+                    assert ref.lz4f_decompress(frames[i].tobytes(), len(want)) == want
+                lits.append(want)
+            print(f"dedup literals size={size}", flush=True)
+            bufs = ctx.decompress_to_device([ref.lz4f_compress(l) for l in lits if l], [len(l) for l in lits if l])
+            live = [l for l in lits if l]
+            # a chunk made of every stream's LAST bytes (the run ends where the block's mapping ends) and first bytes
+            src, ln, blob = [], [], b""
+            for b, l in zip(bufs, live):
+                k = min(len(l), 4099)
+                src += [b.dptr + len(l) - k, b.dptr]; ln += [k, min(len(l), 17)]; blob += l[len(l) - k:] + l[:min(len(l), 17)]
+            outs, digs = ctx.gather_md5([np.array(src, np.uint64)], [np.array(ln, np.uint32)], [np.empty(len(blob), np.uint8)])
+            assert outs[0].tobytes() == blob and digs[0] == hashlib.md5(blob).digest()
+            del bufs
+            n_cases += 1
+    print(f"OK dedup ({n_cases} cases)")
+
+
 _POOL_DATA = {}
 
 
@@ -284,4 +327,4 @@ def run_smoke():
 if __name__ == "__main__":
     what = sys.argv[1]
     {"probe_in": lambda: run_probe("probe_in"), "probe_over": lambda: run_probe("probe_over"), "probe_under": lambda: run_probe("probe_under"),
-     "lz4": run_lz4, "batch": run_batch, "lz4d": run_lz4d, "cdc": run_cdc, "frames512": run_frames512, "smoke": run_smoke}[what]()
+     "lz4": run_lz4, "batch": run_batch, "lz4d": run_lz4d, "cdc": run_cdc, "dedup": run_dedup, "frames512": run_frames512, "smoke": run_smoke}[what]()

@@ -35,8 +35,8 @@ def test_the_fence_works_one_byte_past_and_one_byte_before():
         assert "about to read" in p.stdout
 
 
-@pytest.mark.parametrize("case,env", [("lz4", {}), ("lz4", {"SKYHIP_FRAMES_MIN": 1}), ("batch", {}), ("lz4d", {}), ("cdc", {}), ("smoke", {})],
-                         ids=["lz4-block-queue", "lz4-frames-in-place", "host-batch", "lz4d", "cdc", "smoke"])
+@pytest.mark.parametrize("case,env", [("lz4", {}), ("lz4", {"SKYHIP_FRAMES_MIN": 1}), ("batch", {}), ("lz4d", {}), ("cdc", {}), ("dedup", {}), ("smoke", {})],
+                         ids=["lz4-block-queue", "lz4-frames-in-place", "host-batch", "lz4d", "cdc", "dedup-on-the-wire", "smoke"])
 def test_kernels_stay_inside_their_buffers_on_the_gpu(case, env):
     p = _run(case, **env)
     assert p.returncode == 0 and f"OK {case}" in p.stdout, \
