@@ -292,12 +292,9 @@ def main():
     pool = mp.get_context("fork").Pool(pool_n) if (args.verify != "none" or want_cpu) else None
 
     log(f"host unit of {unit_bytes >> 20} MiB generated, CPU pool of {pool_n} forked")
-    if args.cdc:
-        # configs[2] keeps four kernel streams of two contexts busy at once (compressor, whole-chunk digests, CDC chain, x 2 steps in flight).  The HIP runtime
-        # maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin, and kernels of streams that share a queue run one after
-        # the other: with 12 streams on 4 queues a step's CDC chain sat behind the OTHER step's 150 ms digest launch (GPU calls r5g-r5m: 352-412 GiB/s at 4
-        # queues, 410-423 at 16 with the library's filler-sized CDC grids).  Read by the runtime when it initialises, i.e. at `import torch` below.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (configs[2] keeps four kernel streams of two contexts busy at once.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues --
+    # default 4 -- round-robin, and kernels of streams that share a queue run one after the other; 8 / 16 / 24 / 32 queues were all measured for `--cdc`
+    # (GPU calls r5g-r6f) and every one of them showed a second mode at 250-300 ms per step next to its 140-160: the default count is what is stable.)
     import torch  # noqa: E402  (imported before libskyhip so both share one HIP runtime; no device touched before the fork above)
 
     if emu:

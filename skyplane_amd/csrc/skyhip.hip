@@ -438,7 +438,7 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         { const char* e = getenv("SKYHIP_MD5_WG"); const int v = e ? atoi(e) : 0; if (v >= 64 && v <= 256 && v % 64 == 0) { c->md5_wg = v; c->md5_wg_env = true; } }
 #ifdef SKY_WITH_CDC
         c->cdc.segmd5_grid = (uint32_t)c->lz4s_grid * 32u;
-        c->cdc.gear_grid_beside = (uint32_t)c->lz4s_grid * 4u; c->cdc.segmd5_grid_beside = (uint32_t)c->lz4s_grid * 8u;
+        c->cdc.gear_grid_beside = c->cdc.gear_grid; c->cdc.segmd5_grid_beside = c->cdc.segmd5_grid;      // (see sky_cdc_run: bounded grids were measured and are NOT the default)
         if (const char* e = getenv("SKYHIP_GEAR_BESIDE")) { const int v = atoi(e); if (v > 0) c->cdc.gear_grid_beside = (uint32_t)c->lz4s_grid * (uint32_t)v; }        // (tuning: wavefronts per CU)
         if (const char* e = getenv("SKYHIP_SEGMD5_BESIDE")) { const int v = atoi(e); if (v > 0) c->cdc.segmd5_grid_beside = (uint32_t)c->lz4s_grid * (uint32_t)v; }
         c->cdc.gear_grid = (uint32_t)c->lz4s_grid * 32u;      // wavefronts of sky_gear_candidates: what the chip holds when the kernel has it to itself
