@@ -690,9 +690,7 @@ def test_source_lane_publishes_a_batch_while_the_next_one_is_on_the_device(tmp_p
         assert comp._process_in_lane(reqs[k:k + 3], 0) is None
     for fut in list(comp._tls.finishing.values()):
         fut.result(timeout=30)
-    got = []
-    while not q_out.q.empty():
-        got.append(q_out.q.get().chunk.chunk_id)
+    got = [q_out.q.get(timeout=10).chunk.chunk_id for _ in reqs]      # (a multiprocessing queue: what a thread put may take a moment to become visible)
     assert got == [cr.chunk.chunk_id for cr in reqs]          # completed in order, by the helper
     assert {"out0", "out1", "lit0", "lit1"} <= set(comp._arenas)
     payloads = [sidecar.compressed_path(src, cr.chunk.chunk_id).read_bytes() for cr in reqs]
@@ -708,8 +706,13 @@ def test_source_lane_publishes_a_batch_while_the_next_one_is_on_the_device(tmp_p
     assert all(dec.process_batch(reqs))
     for cr, c in zip(reqs, chunks):
         assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
-    recs = []
-    while not src.chunk_status_queue.empty():
-        recs.append(src.chunk_status_queue.get())
-    assert sum(r["state"] == "complete" for r in recs) == 9
+    import queue as pyqueue
+
+    done = 0
+    try:
+        while done < 9:
+            done += src.chunk_status_queue.get(timeout=10)["state"] == "complete"
+    except pyqueue.Empty:
+        pass
+    assert done == 9
     comp.worker_exit(0)
