@@ -656,6 +656,7 @@ class GatewayHipDecompress(GatewayHipCompress):
         # "arena" hand-off (a batch in the making while the previous one's chunks are being uploaded and deleted), 0 with "files"; the slot size is the
         # chunk length of the lane's first batch (other lengths take the write path).
         self.out_slots = (self.max_batch if self.handoff == "arena" else 0) if out_slots is None else int(out_slots)
+        self.out_slot_bytes = 1 << 30          # ... and at most this many bytes of slot files per lane
         assert dedup_store in ("memory", "files")
         self.dedup_store = dedup_store         # "files": the segment store lives in the chunk directory and several worker processes share it
         # dedup on the wire (dedup_wire.py): payloads that are recipes are rebuilt from their literal stream and the segments earlier chunks
@@ -873,7 +874,8 @@ class GatewayHipDecompress(GatewayHipCompress):
             if size <= 0:
                 return None
             tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
-            ls = shm_arena.LinkSlots(self.chunk_store.get_chunk_file_path("x").parent, tag, size, self.out_slots)
+            n_slots = max(2, min(self.out_slots, self.out_slot_bytes // size))      # (page-locked tmpfs: bounded in bytes too -- 64 MiB chunks get 16 slots per lane, not 64)
+            ls = shm_arena.LinkSlots(self.chunk_store.get_chunk_file_path("x").parent, tag, size, n_slots)
             ls.register(ctx)
             self._tls.link_slots = ls
         return ls
