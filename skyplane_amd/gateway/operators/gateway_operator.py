@@ -869,8 +869,16 @@ class GatewayHipDecompress(GatewayHipCompress):
         if self.out_slots <= 0 or not chunk_lens:
             return None
         ls = getattr(self._tls, "link_slots", None)
+        # the slots are as long as the chunks of the transfer: the most frequent length of the batch at hand.  A lane whose first batch held only an
+        # object's short tail is not stuck with that size (the arena's lesson): when a batch's usual length differs and no slot is in use, the
+        # slot files are made again -- and that is said once per change
+        lens_sorted = sorted(chunk_lens)
+        size = max(set(lens_sorted), key=lens_sorted.count)
+        if ls is not None and size > 0 and size != ls.size and ls.idle():
+            print(f"[{self.handle}] slot files of {ls.size} bytes do not fit this transfer's chunks of {size} bytes: made again", flush=True)
+            ls.close()
+            ls = self._tls.link_slots = None
         if ls is None:
-            size = max(chunk_lens)
             if size <= 0:
                 return None
             tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"

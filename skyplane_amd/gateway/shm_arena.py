@@ -355,6 +355,16 @@ class LinkSlots:
                 self._next = (got[-1] + 1) % self.n
         return got
 
+    def idle(self) -> bool:
+        """No slot is taken or still published (every chunk that went through one has been uploaded and deleted)."""
+        with self._lock:
+            if any(self._busy):
+                return False
+            try:
+                return all(os.stat(p).st_nlink == 1 for p in self.paths)
+            except FileNotFoundError:
+                return False
+
     def publish(self, slot: int, final: Path):
         tmp = final.with_name(final.name + ".lnk")
         try:

@@ -432,6 +432,40 @@ def test_decoded_chunks_are_published_as_hard_links_to_page_locked_slot_files(tm
     assert dst.get_chunk_file_path(first[1].chunk.chunk_id).read_bytes() == reqs[1][1]      # ... nor by the slots going away
 
 
+def test_slot_files_follow_the_transfers_chunk_length(tmp_path, monkeypatch, capsys):
+    """A lane whose FIRST batch held only an object's short tail must not keep tail-sized slot files for the rest of the transfer (the arena's lesson,
+    ADVICE r4): once nothing is published in them they are made again for the length the chunks really have."""
+    from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    size = 30_000
+    src, _, _, reqs = _make_store(tmp_path / "src", 4, size=size)
+    tail = (reqs[0][0], reqs[0][1][:7_777])
+    tail[0].chunk.chunk_length_bytes = len(tail[1])
+    reqs[0] = tail
+    dst = ChunkStore(tmp_path / "dst" / "chunks")
+    q_in, q_out = GatewayQueue(), GatewayQueue()
+    dst.add_partition("0", q_in)
+    op = GatewayHipDecompress("gpu_decompress_0", "local:dst", q_in, q_out, Event(), Queue(), dst, n_processes=1, max_batch=4, device_ids=[0],
+                              context_factory=lambda d, mc, mb: _InPlaceDecodeContext(d, mc, mb), out_slots=2)
+    op.worker_id = 0
+    for cr, data in reqs:
+        dst.get_compressed_file_path(cr.chunk.chunk_id).write_bytes(ref.lz4f_compress_port(data))
+    assert op.process_batch([reqs[0][0]]) == [True]                               # the tail alone: slots of 7777 bytes
+    assert {f.stat().st_size for f in (tmp_path / "dst" / "chunks").glob("_outslot_*")} == {7_777}
+    assert op.process_batch([reqs[1][0]]) == [True]                               # a full chunk while the tail is still published: plain write, same slots
+    assert {f.stat().st_size for f in (tmp_path / "dst" / "chunks").glob("_outslot_*")} == {7_777}
+    dst.get_chunk_file_path(reqs[0][0].chunk.chunk_id).unlink()                   # the daemon is done with the tail
+    assert op.process_batch([reqs[2][0], reqs[3][0]]) == [True, True]
+    slots = list((tmp_path / "dst" / "chunks").glob("_outslot_*"))
+    assert {f.stat().st_size for f in slots} == {size} and "made again" in capsys.readouterr().out
+    inodes = {f.stat().st_ino for f in slots}
+    assert all(dst.get_chunk_file_path(reqs[k][0].chunk.chunk_id).stat().st_ino in inodes for k in (2, 3))
+    for cr, data in reqs[1:]:
+        assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == data
+    op.worker_exit(0)
+
+
 def test_decompress_operator_checksum_mismatch_is_an_error(tmp_path, monkeypatch):
     from skyplane_amd.gateway.operators.gateway_operator import GatewayHipDecompress
 
