@@ -71,9 +71,12 @@ def run_cdc():
             want = [int(x) for x in ref.gear_cdc(data)]
             for guard in ("end", "start"):
                 e = emulib.EmuCdc()
-                prefix, seg_end, fps, first, base, _ = e.run([data], gear, dedup=True, guard=guard)
+                # (literals=True: the literal-stream kernels of dedup on the wire too -- the chunk twice, so that the second copy is all references --
+                # with the streams' buffer fenced like the input)
+                prefix, seg_end, fps, first, base, _, streams = e.run([data, data], gear, dedup=True, guard=guard, literals=True)
                 got = [int(x) for x in seg_end[: int(prefix[1])]]
                 assert got == list(want), (n, name, guard)
+                assert int(prefix[2]) == 2 * int(prefix[1]) and len(streams[0]) + len(streams[1]) <= 2 * n and len(streams[0]) > 0
                 lo = 0
                 for k, hi in enumerate(got):
                     assert fps[k].tobytes() == hashlib.md5(data[lo:hi]).digest(), (n, name, guard, k)

@@ -155,12 +155,16 @@ static void k_segdesc(void* a, uint8_t*) { sky_seg_desc_body(*(SkySegDescArgs*)a
 static void k_segmd5(void* a, uint8_t*) { sky_segment_md5_body(*(SkySegMd5Args*)a); }
 static void k_dins(void* a, uint8_t*) { sky_dedup_insert_body(*(SkyDedupArgs*)a); }
 static void k_dres(void* a, uint8_t*) { sky_dedup_resolve_body(*(SkyDedupArgs*)a); }
+static void k_litplan(void* a, uint8_t*) { sky_lit_plan_body(*(SkyLitArgs*)a); }
+static void k_litgather(void* a, uint8_t*) { sky_lit_gather_body(*(SkyLitArgs*)a); }
+static void k_gruns(void* a, uint8_t*) { sky_gather_runs_body(*(SkyRunArgs*)a); }
 
 // Mirrors sky_cdc_run's launch sequence.  gear: 256 x u64 table (the caller passes the ORACLE's table so a
 // generator mismatch shows up in the GPU tests, not here).  Returns total segments or <0.
 long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, int n, const uint64_t* gear, uint32_t* seg_prefix_out,
              uint32_t* seg_end_out, size_t seg_cap, uint8_t* fps_out, uint64_t* first_seen_out, uint64_t* key_lo, uint64_t* key_hi,
-             uint64_t* first, uint32_t slots_log2, uint64_t seg_base, int dedup, uint32_t* cand_cnt_out) {
+             uint64_t* first, uint32_t slots_log2, uint64_t seg_base, int dedup, uint32_t* cand_cnt_out, uint8_t* lit_out, uint64_t lit_stride,
+             uint32_t* lit_len_out) {
     std::vector<sky_u64> off(in_off, in_off + n);
     std::vector<uint32_t> len(n), tile_prefix(n + 1), cut_prefix(n + 1), ncuts(n), seg_prefix(n + 1);
     uint32_t tiles = 0, slots = 0;
@@ -197,10 +201,24 @@ long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, 
         emu_launch((slots + 255) / 256, 256, 0, k_dres, &da);
         // err[0] = segments that found no slot within the probe bound: reported as "not seen before", not an error
     }
+    if (dedup && lit_out) {      // dedup on the wire, source side (skyhip_dedup_literals): every chunk's NEW segments back to back, at lit_out + i * lit_stride
+        std::vector<uint32_t> lit_off(slots ? slots : 1), lit_len(n ? n : 1);
+        SkyLitArgs la; la.in = in; la.desc = desc.data(); la.first_seen = fs.data(); la.seg_prefix = seg_prefix.data(); la.seg_base = seg_base; la.n_chunks = (uint32_t)n;
+        la.lit_off = lit_off.data(); la.lit_len = lit_len.data(); la.lit = lit_out; la.lit_stride = lit_stride;
+        emu_launch((n + 3) / 4, 256, 0, k_litplan, &la);
+        if (total) emu_launch(total > 9u ? 2 : 1, 256, 0, k_litgather, &la);      // (fewer wavefronts than segments: each copies several)
+        for (int i = 0; i < n; i++) lit_len_out[i] = lit_len[i];
+    }
     for (int i = 0; i <= n; i++) seg_prefix_out[i] = seg_prefix[i];
     for (uint32_t i = 0; i < total; i++) { seg_end_out[i] = seg_end[i]; if (dedup) first_seen_out[i] = fs[i]; }
     memcpy(fps_out, fps.data(), (size_t)total * 16);
     return (long)total;
+}
+
+// skyhip_gather_md5's copy step: run k = len[k] bytes from src[k] to dst[k] (host addresses here)
+void emu_gather_runs(const uint64_t* src, const uint64_t* dst, const uint32_t* len, uint32_t n_runs) {
+    SkyRunArgs ra; ra.src = (const sky_u64*)src; ra.dst = (const sky_u64*)dst; ra.len = len; ra.n_runs = n_runs;
+    if (n_runs) emu_launch(n_runs > 5u ? 2 : 1, 256, 0, k_gruns, &ra);
 }
 #endif
 

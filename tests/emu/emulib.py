@@ -24,7 +24,9 @@ def lib() -> C.CDLL:
         l.emu_slot_bytes.restype = C.c_uint32
         l.emu_decompress.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5
         l.emu_decompress.restype = C.c_int
-        l.emu_cdc.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+        l.emu_cdc.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        l.emu_gather_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        l.emu_gather_runs.restype = None
         l.emu_cdc.restype = C.c_long
         _lib = l
     return _lib
@@ -135,7 +137,9 @@ class EmuCdc:
         self.first = np.full(1 << slots_log2, 0xFFFFFFFFFFFFFFFF, np.uint64)
         self.seg_base = 0
 
-    def run(self, chunks, gear, dedup=True, guard=None):
+    def run(self, chunks, gear, dedup=True, guard=None, literals=False):
+        """literals=True (with dedup): also every chunk's literal stream -- its NEW segments back to back, put together by the shipping sky_lit_plan /
+        sky_lit_gather kernels (skyhip_dedup_literals) -- as a seventh result, a list of bytes; with a guard the streams' buffer ends at a fenced page."""
         n = len(chunks)
         lens = np.array([len(c) for c in chunks], np.uint64)
         in_off, in_addr, _keep_in = _pack_inputs(chunks, guard)
@@ -147,14 +151,38 @@ class EmuCdc:
         ntiles = int(sum((len(c) + 32767) // 32768 for c in chunks))
         cc = np.zeros(max(ntiles, 1), np.uint32)
         gear = np.ascontiguousarray(gear, np.uint64)
+        lit_addr, lit_stride, lit_len, lit_view = None, 0, np.zeros(max(n, 1), np.uint32), None
+        if literals and dedup and n:
+            lit_stride = max(int(lens.max()), 1)
+            if guard is None:
+                lit_view = np.full(n * lit_stride + 64, 0xEE, np.uint8)
+                lit_addr = lit_view.ctypes.data
+            else:
+                _keep_lit = Guarded(n * lit_stride, guard, fill=0xEE)
+                lit_view, lit_addr = _keep_lit.view, _keep_lit.addr
         tot = lib().emu_cdc(in_addr, in_off.ctypes.data, lens.ctypes.data, n, gear.ctypes.data, prefix.ctypes.data, seg_end.ctypes.data, cap,
                             fps.ctypes.data, first.ctypes.data, self.key_lo.ctypes.data, self.key_hi.ctypes.data, self.first.ctypes.data,
-                            self.slots_log2, self.seg_base, int(dedup), cc.ctypes.data)
+                            self.slots_log2, self.seg_base, int(dedup), cc.ctypes.data, lit_addr, lit_stride, lit_len.ctypes.data)
         assert tot >= 0, tot
         base = self.seg_base
         if dedup:
             self.seg_base += tot
-        return prefix, seg_end[:tot], fps[:tot], (first[:tot] if dedup else None), base, cc[:ntiles]
+        res = (prefix, seg_end[:tot], fps[:tot], (first[:tot] if dedup else None), base, cc[:ntiles])
+        if literals and dedup:
+            streams = [lit_view[i * lit_stride:i * lit_stride + int(lit_len[i])].tobytes() for i in range(n)]
+            for i in range(n):      # nothing written behind a stream's end
+                assert (lit_view[i * lit_stride + int(lit_len[i]):(i + 1) * lit_stride] == 0xEE).all(), f"chunk {i}: wrote past its literal stream"
+            res += (streams,)
+        return res
+
+
+def gather_runs(src_addrs, dst_addrs, lens):
+    """sky_gather_runs (skyhip_gather_md5's copy step) under the emulator: run k = lens[k] bytes from src_addrs[k] to dst_addrs[k] (host addresses)."""
+    src = np.ascontiguousarray(src_addrs, np.uint64)
+    dst = np.ascontiguousarray(dst_addrs, np.uint64)
+    ln = np.ascontiguousarray(lens, np.uint32)
+    assert src.size == dst.size == ln.size
+    lib().emu_gather_runs(src.ctypes.data, dst.ctypes.data, ln.ctypes.data, int(ln.size))
 
 
 def decompress(frames, caps, guard=None):

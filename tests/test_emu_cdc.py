@@ -98,3 +98,39 @@ def test_emu_dedup_overfull_table_is_not_an_error():
         assert (first[:n] <= idx).all()
         seen_total += n
     assert seen_total > 3 * 1024
+
+
+def test_emu_literal_streams_and_run_gather_match_a_host_gather():
+    """The dedup-on-the-wire device kernels under the emulator: sky_lit_plan + sky_lit_gather (skyhip_dedup_literals) put every chunk's NEW segments back to
+    back exactly as numpy does from the same cuts and first-seen indices, across two calls that share the table, with ragged and tiny chunks; and
+    sky_gather_runs (skyhip_gather_md5) copies byte runs of any length and alignment to where they belong and nowhere else."""
+    from skyplane_amd.gateway import dedup_wire
+
+    gear = ref.gear_table()
+    cdc = emulib.EmuCdc(slots_log2=12)
+    stream = synth.dedup_stream(6 * 200_000, dup_fraction=0.5, config_id=3)
+    chunks = [stream[i * 200_000:(i + 1) * 200_000].tobytes() for i in range(6)]
+    chunks[4] = chunks[1]                                    # nothing but references in the second call
+    chunks[5] = chunks[5][:70_001]
+    chunks.append(b"x" * 13)
+    for batch in (chunks[:3], chunks[3:]):
+        prefix, seg_end, fps, first, base, _cc, streams = cdc.run(batch, gear, dedup=True, literals=True)
+        for i, c in enumerate(batch):
+            lens, kinds, _sl = dedup_wire.classify_segments(prefix.astype(np.uint64), seg_end, first, base, i)
+            ends = np.cumsum(lens.astype(np.int64))
+            want = b"".join(c[e - l:e] for e, l, k in zip(ends, lens, kinds) if k == dedup_wire.KIND_LITERAL)
+            assert streams[i] == want, (i, len(streams[i]), len(want))
+    assert streams[1] == b""                                  # chunks[4] == chunks[1]: every segment was seen in the first call
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, 300_000, dtype=np.uint8)
+    dst = np.full(400_000, 0xEE, np.uint8)
+    runs, pos = [], 7
+    for n in [1, 2, 15, 16, 17, 63, 64, 65, 255, 4096, 70_001] + [int(x) for x in rng.integers(1, 3000, 40)]:
+        o = int(rng.integers(0, src.size - n))
+        runs.append((o, pos, n))
+        pos += n + int(rng.integers(0, 3))                   # sometimes touching, sometimes a gap that must stay untouched
+    emulib.gather_runs([src.ctypes.data + o for o, _, _ in runs], [dst.ctypes.data + d for _, d, _ in runs], [n for _, _, n in runs])
+    want = np.full(400_000, 0xEE, np.uint8)
+    for o, d, n in runs:
+        want[d:d + n] = src[o:o + n]
+    assert np.array_equal(dst, want)
