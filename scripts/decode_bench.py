@@ -9,6 +9,7 @@ reference sender puts on the wire), replicated to --frames frames resident in HB
 frame's output is compared with its chunk.  One JSON line: GB/s of decoded output, the HBM roofline at the algorithmic traffic (frame bytes read + decoded
 bytes written per launch; the launch time is the library's own hipEvent pair around scan + decode), and liblz4's LZ4F_decompress on the host cores beside it."""
 import argparse
+from pathlib import Path
 import json
 import os
 import sys
@@ -76,6 +77,14 @@ def main():
                          "achieved": round((raw + comp) / kern / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round((raw + comp) / kern / 8e12, 5), "traffic": None,
                          "launch_ms": round(kern * 1e3, 3), "algorithmic_bytes_per_launch": raw + comp},
             "verified": {"outputs_equal_chunks": ok, "checked": min(n, 16)}}
+    # HBM-side traffic of the decode kernels: a committed rocprofv3 --pmc measurement of THIS command (scripts/dev/pmc_decode.sh -> profiles/traffic_decode.json),
+    # quoted only for the frame kind and batch size it was taken on
+    tf = Path(__file__).resolve().parents[1] / "profiles" / "traffic_decode.json"
+    if tf.exists():
+        t = json.loads(tf.read_text()).get(f"{a.kind}:{n}")
+        if t:
+            line["roofline"]["traffic"] = int(raw * t["bytes_per_output_byte"])
+            line["roofline"]["traffic_source"] = t["source"]
     if not a.no_cpu_baseline:
         import multiprocessing as mp
         try:
