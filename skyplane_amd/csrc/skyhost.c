@@ -6,9 +6,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "skyhost.h"      /* the ABI declared in include/ */
 
 typedef struct { uint64_t lo, hi, addr; uint32_t len, used; } sky_slot;      /* 32 bytes */
-typedef struct skyhost_map { sky_slot* s; uint64_t mask, count; } skyhost_map;
+struct skyhost_map { sky_slot* s; uint64_t mask, count; };
 
 static uint64_t mix(uint64_t lo, uint64_t hi) { uint64_t x = lo ^ (hi * 0x9E3779B97F4A7C15ull); x ^= x >> 32; return x * 0xD6E8FEB86659FD93ull; }
 

@@ -580,6 +580,14 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert b"device" in lib.skyhip_strerror(-6)
     h = ctypes.c_void_p()
     assert lib.skyhip_create(0, 0, 1, ctypes.byref(h)) == -1     # argument validation needs no GPU
+    # the host-side helper library (plain C: the device store's fingerprint map) against ITS header
+    from skyplane_amd import _hostlib
+
+    hl = _hostlib.load()
+    declared = set(re.findall(r"\b(skyhost_[a-z0-9_]+)\s*\(", (ROOT / "include" / "skyhost.h").read_text()))
+    assert declared == {"skyhost_map_new", "skyhost_map_free", "skyhost_map_count", "skyhost_map_put", "skyhost_map_get"}
+    for name in declared:
+        assert hasattr(hl, name), name
 
 
 def _gloo_worker(rank, world, port, n_chunks, out_q):
