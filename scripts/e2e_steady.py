@@ -210,6 +210,7 @@ def main():
                                 dedup_epoch_bytes=a.dedup_epoch_mb << 20, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
                                    max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None,
+                                   dedup_wire=a.dedup_wire,      # (what the planner patch passes: INTEGRATION 10 -- three lanes by default then)
                                    out_slots=None if a.out_slots < 0 else a.out_slots, fill_wait_s=None if a.dst_fill_wait_ms < 0 else a.dst_fill_wait_ms / 1e3, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
