@@ -714,6 +714,13 @@ def test_steady_state_e2e_script_with_emulated_device():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["verified"] and r["chunks"] == 10 and r["workers"] == 2
+    # the same with the harness standing in for write_object_store + the daemon's clean-up (every chunk checked and deleted on arrival: what frees the
+    # destination's slot files), two lanes per worker by default
+    p = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_steady.py"), "--context", "emu", "--chunks", "12", "--chunk-kib", "64",
+                        "--connections", "2", "--max-batch", "4", "--workers", "1", "--dst-consume"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["dst_consume"]["chunks_deleted_on_arrival"] == 14 and r["dst_consume"]["hashed_on_the_cpu"] >= 1
 
 
 def test_lanes_collect_before_a_call(tmp_path):
