@@ -183,24 +183,33 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def run_secondary(extra, steps, warmup):
-    """One of the other single-GPU configurations as its own process (own HIP context, own CPU pool): returns its JSON line as a dict, or the reason
-    it has none.  The same file, the same verification, fewer steps."""
+def run_secondary(extra, steps, warmup, script=None):
+    """One of the other single-GPU measurements as its own process (own HIP context, own CPU pool): returns its JSON line as a dict, or the reason
+    it has none.  script=None: this very file (the same verification, fewer steps); otherwise one of scripts/*.py that print one JSON line."""
     import subprocess
 
-    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary"] + extra
+    if script is None:
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary"] + extra
+        shown = "python bench.py " + " ".join(cmd[2:])
+    else:
+        cmd = [sys.executable, str(ROOT / "scripts" / script)] + extra
+        shown = f"python scripts/{script} " + " ".join(extra)
     t0 = time.perf_counter()
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, timeout=600 if script is None else 150,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
         line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not line:
-            return {"error": f"exit code {p.returncode}", "command": " ".join(cmd[1:])}
+            return {"error": f"exit code {p.returncode}", "command": shown}
         r = json.loads(line[-1])
     except subprocess.TimeoutExpired:
-        return {"error": "timeout after 600 s", "command": " ".join(cmd[1:])}
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_step", "verified")
-    out = {k: r[k] for k in keep if k in r}
-    out["command"] = "python bench.py " + " ".join(cmd[2:])
+        return {"error": "timeout", "command": shown}
+    if script is None or "metric" in r:
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_step", "verified", "cpu_baseline", "per_gpu")
+        out = {k: r[k] for k in keep if k in r}
+    else:
+        out = r
+    out["command"] = shown
     out["run_s"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -230,6 +239,7 @@ def main():
                                                                 "SKYHIP_FRAMES_MIN=0 runs; block scratch = 8.06 MiB per chunk); the default run writes frames in place and never uses it")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] / configs[3]-on-one-GPU runs appended to the default 1-GPU line")
     ap.add_argument("--secondary-steps", type=int, default=16)
+    ap.add_argument("--secondary-budget-s", type=float, default=100.0, help="no further secondary run is STARTED once the ones before it took this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", choices=["auto", "silesia", "mixed"], default="auto",
                     help="auto = silesia (configs[1]) on one GPU, mixed (configs[3]) on several")
@@ -265,6 +275,16 @@ def main():
         for key, extra in (("configs[2]", ["--cdc"]), ("configs[3] stream on one GPU", ["--stream", "mixed", "--chunks", "16384"])):
             log(f"secondary run {key}: bench.py {' '.join(extra)} --steps {args.secondary_steps}")
             secondary_res[key] = run_secondary(extra, args.secondary_steps, 1)
+        # the rest of the path: the destination's decoder on this library's frames at a large batch and on the reference sender's default
+        # (block-linked) frames at an operator's batch, and the host-buffer entry points the operators call (PCIe included) -- each verified by its script
+        for key, script, extra in (("f1 decode: own frames x 1024", "decode_bench.py", ["--frames", "1024", "--kind", "ours", "--no-cpu-baseline"]),
+                                   ("f1 decode: reference-default linked frames x 32", "decode_bench.py", ["--frames", "32", "--kind", "linked"]),
+                                   ("host buffers (PCIe included) x 256", "host_path_bench.py", ["--chunks", "256", "--skip-pageable", "--reps", "2"])):
+            if time.perf_counter() - _T0 > args.secondary_budget_s:
+                secondary_res[key] = {"skipped": f"the secondary runs before it used up their {args.secondary_budget_s:.0f} s"}
+                continue
+            log(f"secondary run {key}: scripts/{script} {' '.join(extra)}")
+            secondary_res[key] = run_secondary(extra, 0, 0, script=script)
 
     # ---- host unit (deterministic), then the CPU pool, then -- and only then -- the HIP runtime ----
     t0 = time.perf_counter()
@@ -468,6 +488,16 @@ def main():
     tm = _Tm()
     for f in ("lz4_ms", "layout_ms", "gather_ms", "md5_ms", "cdc_ms", "lz4_launches", "lz4_in_bytes", "lz4_out_bytes", "md5_launches", "md5_in_bytes"):
         setattr(tm, f, sum(getattr(t, f) for t in tms))
+    # configs[3] asks for per-GPU AND aggregate rates: every rank's own clock and kernel times travel to rank 0 (one all_gather of nine doubles, outside
+    # the timed region); a slow GPU, or a rank whose streams share a hardware queue, shows up as its own row
+    mine = [float(rank), _local, tm.lz4_ms, tm.md5_ms, tm.cdc_ms, float(tm.lz4_in_bytes), float(tm.lz4_out_bytes), float(max(tm.lz4_launches, 1)), float(n_chunks)]
+    if world > 1:
+        me = torch.tensor(mine, dtype=torch.float64, device=dev)
+        rows = [torch.empty_like(me) for _ in range(world)]
+        dist.all_gather(rows, me)
+        per_rank = [r_.tolist() for r_ in rows]
+    else:
+        per_rank = [mine]
     last_lane = (args.steps - 1) % depth if args.steps >= depth else 0
     out_len = lasts[last_lane]["out_len"]
     md5 = lasts[last_lane]["md5"] if md5_lanes == 0 else md5_lasts[(args.steps - 1) % md5_lanes if args.steps >= md5_lanes else 0]["md5"]
@@ -572,6 +602,25 @@ def main():
             "verified": {"digests_vs_hashlib": verified["digests"], "frames_vs_liblz4": verified["frames"], "digest_of_digests": dd, "all_ranks_ok": bool(ok)},
             "setup_s": round(gen_s, 1),
         }
+        per_gpu = []
+        for r_, loc, lz, md, cd, ib, ob, nl, nc_ in per_rank:
+            a_ = (ib + ob) / (lz / 1e3) / 1e9 if lz > 0 else 0.0
+            per_gpu.append({"rank": int(r_), "GiBps": round(nc_ * cb * args.steps / loc / 2**30, 4), "elapsed_s": round(loc, 4), "lz4_ms_per_step": round(lz / args.steps, 3),
+                            "md5_ms_per_step": round(md / args.steps, 3), **({"cdc_ms_per_step": round(cd / args.steps, 3)} if args.cdc else {}),
+                            "avg_launch_ms": round(lz / nl, 4), "frac": round(a_ / HBM_PEAK_GBPS, 5)})
+        res["per_gpu"] = per_gpu
+        res["aggregate"] = {"GiBps": res["value"], "sum_of_per_gpu_GiBps": round(sum(g["GiBps"] for g in per_gpu), 3),
+                            "slowest_rank": int(min(per_gpu, key=lambda g: g["GiBps"])["rank"]), "timing": "value = all ranks' bytes / MAX over ranks of the barrier-to-barrier time"}
+        if world > 1 or args.stream == "mixed":
+            # The N = 1 point of THIS workload (a bare `--gpus 1` runs configs[1], another stream: dividing the N-GPU value by N x that number mixes two
+            # workloads).  A scaling sweep's N = 1 run is `python bench.py --gpus 1 --stream mixed --chunks 16384`; the last such run committed with the
+            # tree is quoted here so that the N-GPU line carries its own like-for-like reference.
+            nf = ROOT / "profiles" / "n1_reference.json"
+            if nf.exists() and not emu:
+                n1 = json.loads(nf.read_text()).get("cdc" if args.cdc else stream)
+                if n1:
+                    res["n1_reference"] = {**n1, "quoted": True}
+                    res["scaling_efficiency_vs_n1_reference"] = round(value / (world * n1["GiBps"]), 4)
         if md5_alone_ms:
             hbm_in = HBM_PEAK_GBPS * 1e9 / (1.0 + comp_bytes / (n_chunks * cb)) / 2**30      # input GiB/s at which N + C bytes saturate the HBM peak
             chain = n_chunks * cb / (md5_alone_ms / 1e3) / 2**30
@@ -590,19 +639,33 @@ def main():
             if t:
                 per_launch_in = tm.lz4_in_bytes / max(tm.lz4_launches, 1)
                 res["roofline"]["traffic"] = int(per_launch_in * (t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"]))
-                res["roofline"]["traffic_source"] = t["source"]
+                # (a quoted ratio x this run's bytes, NOT a counter read in this run: PMC passes serialise kernels and cannot ride in a timed bench)
+                res["roofline"]["traffic_source"] = f"QUOTED from profiles/traffic.json ({t.get('measured', 'round 5, GPU calls r5p-r5r')}), scaled by this run's input bytes per launch: " + t["source"]
                 # The STAGE reads the stream more than once: whole-chunk MD5 is a second pass over the same bytes -- it cannot ride the
                 # compressor's LDS copy: a chain consumes its chunk at ~100 MB/s, a workgroup eats a chunk at ~2.3 GB/s --, FETCH 1.0 B per input byte with
                 # no re-reads (profiles/r3_pmc_traffic_kernels.txt); with --cdc the candidates kernel reads it again with a 64-byte warm-up per 512 (x 1.125) and
                 # the segment digests once more.  SURVEY 8d's algorithmic figure (N + C) counts one read.
-                extra = 1.0 + ((1.125 + 1.0) if args.cdc else 0.0)
+                tm5 = json.loads(tf.read_text()).get("sky_md5_chunks:any")
+                _md5_part = (f"sky_md5_chunks ({tm5['measured']})", tm5["fetch_bytes_per_input_byte"]) if tm5 else ("sky_md5_chunks (one read, measured r3)", 1.0)
+                extra = _md5_part[1] + ((1.125 + 1.0) if args.cdc else 0.0)
                 res["roofline"]["stage_traffic"] = {
                     "bytes_per_input_byte": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"] + extra, 4),
                     "algorithmic_bytes_per_input_byte": round(1.0 + tm.lz4_out_bytes / max(tm.lz4_in_bytes, 1), 4),
-                    "parts": {"compressor (measured)": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"], 4), "sky_md5_chunks (one read, measured r3)": 1.0,
+                    "parts": {"compressor (measured)": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"], 4), _md5_part[0]: _md5_part[1],
                               **({"sky_gear_candidates (512 + 64 bytes per lane)": 1.125, "sky_segment_md5 (one read)": 1.0} if args.cdc else {})},
                     "note": "the digest(s) and the CDC kernels are separate passes over the resident stream by construction: a serial chain per chunk / per segment "
                             "cannot share the compressor's one-block-at-a-time LDS copy"}
+        # The STEP's own fraction, next to the dominant kernel's: algorithmic bytes of a step (N + C) over the step's wall time.  With --cdc the step is
+        # compressor + candidates + segment digests + whole-chunk digests sharing the chip (their times overlap and SUM in chip time, profiles/r5_cdc.txt):
+        # the compressor's launch-level `frac` alone overstates what the stage reaches.
+        step_s = elapsed / args.steps
+        step_alg = (n_chunks * cb + comp_bytes) * (world if world > 1 else 1)
+        res["roofline"]["step"] = {"algorithmic_bytes": int(step_alg), "ms": round(step_s * 1e3, 3), "achieved": round(step_alg / step_s / 1e9, 2),
+                                   "frac": round(step_alg / step_s / 1e9 / (HBM_PEAK_GBPS * world), 5),
+                                   "kernels_ms_per_step": {kname: round(tm.lz4_ms / args.steps, 3), "sky_md5_chunks": round(tm.md5_ms / args.steps, 3),
+                                                           **({"sky_frame_layout": round(tm.layout_ms / args.steps, 3), "sky_frame_gather": round(tm.gather_ms / args.steps, 3)} if not in_place else {}),
+                                                           **({"sky_gear_candidates + sky_gear_select + sky_segment_md5 + sky_dedup_*": round(tm.cdc_ms / args.steps, 3)} if args.cdc else {})},
+                                   "note": "kernel times are HIP-event spans on their own streams and overlap each other (and, with two steps in flight, the neighbouring step): they do not add up to ms"}
         if args.cdc:
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
             prefix, cuts, fps, first, base = ctxs[last_lane].cdc_results(n_chunks, in_len)      # (the context that ran the last step)

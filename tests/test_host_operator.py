@@ -652,6 +652,10 @@ def test_bench_py_rank_logic_world2_gloo():
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 2 and r["config"]["workload"].startswith("configs[3]: 2 MI355X")
     assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 8 and r["verified"]["frames_vs_liblz4"] == 8
     assert r["value"] > 0 and abs(r["value"] - 2 * 8 * 131072 * 2 / (r["ms_per_step"] * 2 / 1e3) / 2**30) < 0.01 * r["value"] + 1e-3
+    # configs[3] "per-GPU + aggregate": one row per rank from that rank's own clock and kernel timers, the aggregate beside them
+    assert [g["rank"] for g in r["per_gpu"]] == [0, 1] and all(g["GiBps"] > 0 and g["elapsed_s"] > 0 and "lz4_ms_per_step" in g and "frac" in g for g in r["per_gpu"])
+    assert r["aggregate"]["GiBps"] == r["value"] and r["aggregate"]["sum_of_per_gpu_GiBps"] >= r["value"] - 0.002 and r["aggregate"]["slowest_rank"] in (0, 1)
+    assert r["roofline"]["step"]["algorithmic_bytes"] > 2 * 8 * 131072 and 0 <= r["roofline"]["step"]["frac"] < 1 and r["roofline"]["step"]["ms"] > 0
 
 
 def test_bench_py_bare_gpus2_launches_itself():
@@ -696,6 +700,7 @@ def test_bench_py_bare_gpus8_dry_run():
     assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["config"]["workload"].startswith("configs[3]: 8 MI355X") and r["config"]["chunks_per_gpu"] == 4
     assert r["verified"]["all_ranks_ok"] and r["verified"]["digests_vs_hashlib"] == 4 and r["verified"]["frames_vs_liblz4"] == 4
     assert abs(r["value"] - 8 * 4 * 131072 / (r["ms_per_step"] / 1e3) / 2**30) < 0.01 * r["value"] + 1e-3      # whole-job aggregate over the eight ranks
+    assert [g["rank"] for g in r["per_gpu"]] == list(range(8)) and all(g["GiBps"] > 0 for g in r["per_gpu"]) and r["aggregate"]["sum_of_per_gpu_GiBps"] >= r["value"] - 0.005
     beats = [l for l in p.stderr.splitlines() if l.startswith("[bench +")]
     assert any("timed region" in l for l in beats) and any("verifying" in l for l in beats) and "secondary" not in r
 
