@@ -42,7 +42,7 @@ def test_emu_empty_frame_is_valid():
     assert ref.lz4f_decompress(frames[0], 0) == b""
 
 
-@pytest.mark.parametrize("n", [1, 4, 5, 11, 12, 13, 14, 63, 64, 65, 127, 128, 129, 4095, 65535, 65536, 65537, 131071, 131072, 131073])
+@pytest.mark.parametrize("n", [1, 4, 5, 11, 12, 13, 14, 55, 56, 57, 63, 64, 65, 119, 120, 121, 127, 128, 129, 4095, 65535, 65536, 65537, 131071, 131072, 131073])
 def test_emu_ragged_lengths(n):
     rng = synth.rng_for(0, n)
     for gen in (synth.gen_text, synth.gen_sparse, synth.gen_random):
