@@ -80,6 +80,14 @@ extern "C" __global__ void __launch_bounds__(SKY_LZ4D_LINK_LANES) sky_lz4_link(S
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_link_body(r, smem);
 }
+extern "C" __global__ void __launch_bounds__(SKY_LZ4R_LANES) sky_lz4_resolve(SkyLz4dResolve r) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4_resolve_body(r, smem);
+}
+extern "C" __global__ void __launch_bounds__(SKY_LZ4R_LANES) sky_lz4_chain(SkyLz4dResolve r) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    sky_lz4_chain_body(r, smem);
+}
 extern "C" __global__ void __launch_bounds__(64) sky_lz4_decode_seq(SkyLz4dRun r) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     sky_lz4_decode_seq_body(r, smem);
@@ -428,6 +436,8 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
         // a context that only ever sees large device-resident batches writes its frames in place and never needs it)
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4s_compress, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4S_LDS_ORIGIN + LZ4S_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_link, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4D_LINK_LDS));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4R_LDS));
+        HIPCHK(c, hipFuncSetAttribute((const void*)sky_lz4_chain, hipFuncAttributeMaxDynamicSharedMemorySize, SKY_LZ4C_LDS));
         c->lz4s_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SKYHIP_LZ4S_GRID")) { const int v = atoi(e); if (v > 0) c->lz4s_grid = v; }
         // frames in place need a chunk per CU (and then some, for balance) to fill the chip; below that the block queue + gather keeps every CU busy

@@ -114,6 +114,7 @@ SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(
 // LDS atomics (workgroup scope): ds_min_u32 without return, ds_add_rtn_u32
 SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SKY_DEV void sky_lds_or_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }      // ds_or_b32, no return
 // flags in LDS that one wavefront of a workgroup stores and the others poll (sky_lz4_link): a real ds_read per poll; sky_wave_yield gives the SIMD to the
 // wavefronts that are being waited for
 SKY_DEV uint32_t sky_lds_poll_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

@@ -69,6 +69,7 @@ SKY_DEV void sky_wave_fence() { emu_collective(EMU_WAVESYNC, 0, 0); }
 SKY_DEV uint32_t sky_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 SKY_DEV void sky_lds_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 SKY_DEV uint32_t sky_lds_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+SKY_DEV void sky_lds_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 SKY_DEV uint32_t sky_lds_poll_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 SKY_DEV sky_u64 sky_lds_poll_u64(const sky_u64* p) { return *(const volatile sky_u64*)p; }
 SKY_DEV void sky_lds_order() { emu_collective(EMU_WAVESYNC, 0, 0); }      // (see sky_wave_fence)

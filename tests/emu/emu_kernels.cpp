@@ -89,6 +89,10 @@ static void k_ddec(void* a, uint8_t* smem) { sky_lz4_decode_body(*(SkyLz4dRun*)a
 static void k_dseq(void* a, uint8_t* smem) { sky_lz4_decode_seq_body(*(SkyLz4dRun*)a, smem); }
 static void k_dparse(void* a, uint8_t* smem) { sky_lz4_parse_body(*(SkyLz4dLink*)a, smem); }
 static void k_dlink(void* a, uint8_t* smem) { sky_lz4_link_body(*(SkyLz4dLink*)a, smem); }
+static void k_dresolve(void* a, uint8_t* smem) { sky_lz4_resolve_body(*(SkyLz4dResolve*)a, smem); }
+static void k_dchain(void* a, uint8_t* smem) { sky_lz4_chain_body(*(SkyLz4dResolve*)a, smem); }
+static int emu_link_resolve = 1;      // which of the library's two ways linked frames take (sky_lz4d_run decides by batch size): 1 = resolve + chain, 0 = sky_lz4_link
+extern "C" void emu_set_link_resolve(int v) { emu_link_resolve = v; }
 
 // mirrors sky_lz4d_run: scan, build work items, decode.  status[i] = decoder code, out_len[i] = decoded bytes.
 int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, int n, uint8_t* out, const uint64_t* out_off,
@@ -125,7 +129,15 @@ int emu_decompress(const uint8_t* in, const uint64_t* in_off, const uint64_t* in
         SkyLz4dLink r; r.a = a; r.item_slot = litems.data(); r.n_items = (uint32_t)litems.size(); r.desc = desc.data(); r.ndesc = ndesc.data();
         r.frames = lframes.data(); r.first_item = lfirst.data(); r.n_frames = (uint32_t)lframes.size();
         emu_launch(((int)litems.size() + 3) / 4, 256, 4 * SKY_D_STAGE_LDS, k_dparse, &r);
-        emu_launch((int)lframes.size(), (int)SKY_LZ4D_LINK_LANES, SKY_LZ4D_LINK_LDS, k_dlink, &r);
+        if (emu_link_resolve) {
+            std::vector<uint16_t> rptr((size_t)litems.size() * SKY_LZ4_BLOCK, 0xCDCD);
+            std::vector<uint8_t> rx((size_t)litems.size() * (SKY_LZ4_BLOCK / 8u), 0xCD);
+            SkyLz4dResolve rr; rr.l = r; rr.ptr = rptr.data(); rr.xbits = rx.data();
+            emu_launch((int)litems.size(), (int)SKY_LZ4R_LANES, SKY_LZ4R_LDS, k_dresolve, &rr);
+            emu_launch((int)lframes.size(), (int)SKY_LZ4R_LANES, SKY_LZ4C_LDS, k_dchain, &rr);
+        } else {
+            emu_launch((int)lframes.size(), (int)SKY_LZ4D_LINK_LANES, SKY_LZ4D_LINK_LDS, k_dlink, &r);
+        }
     }
     if (!items.empty()) {
         SkyLz4dRun r; r.a = a; r.item_slot = items.data(); r.n_items = (uint32_t)items.size();

@@ -185,6 +185,12 @@ def gather_runs(src_addrs, dst_addrs, lens):
     lib().emu_gather_runs(src.ctypes.data, dst.ctypes.data, ln.ctypes.data, int(ln.size))
 
 
+def set_link_resolve(on):
+    """Which of the library's two ways block-linked frames take in decompress(): True = sky_lz4_resolve + sky_lz4_chain (the library's choice up to
+    SKYHIP_LINK_RESOLVE_MAX frames per call), False = sky_lz4_link (larger batches)."""
+    lib().emu_set_link_resolve(1 if on else 0)
+
+
 def decompress(frames, caps, guard=None):
     """frames: list[bytes]; caps: list[int] output capacities. Returns (rc, outputs list[bytes], status list[int]).
     guard: as in process()."""

@@ -10,6 +10,14 @@ from skyplane_amd import synth
 from tests.emu import emulib
 
 
+@pytest.fixture(autouse=True, params=["resolve+chain", "link"])
+def link_path(request):
+    """Block-linked frames take one of two ways through the library (sky_lz4d_run picks by batch size): every test of this file runs through both."""
+    emulib.set_link_resolve(request.param == "resolve+chain")
+    yield request.param
+    emulib.set_link_resolve(True)
+
+
 def test_emu_decode_reference_frames(small_cases):
     names = list(small_cases)
     frames = [ref.lz4f_compress(small_cases[k]) for k in names]       # == lz4.frame.compress(data): linked blocks

@@ -12,14 +12,25 @@ from oracle import ref  # noqa: E402
 from skyplane_amd import synth  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["resolve+chain", "link"])
+def ctx(request):
+    """Block-linked frames take one of two ways through the library -- sky_lz4_resolve + sky_lz4_chain up to SKYHIP_LINK_RESOLVE_MAX frames per call,
+    sky_lz4_link above --: every test of this file runs through both (a context reads the variable at its first linked decode)."""
+    import os
+
     torch.cuda.init()
     from skyplane_amd import hip_ops
 
+    old = os.environ.get("SKYHIP_LINK_RESOLVE_MAX")
+    os.environ["SKYHIP_LINK_RESOLVE_MAX"] = "1000000" if request.param == "resolve+chain" else "0"
     c = hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=8)
+    c.decompress_batch([ref.lz4f_compress(bytes(200000))], [200000])      # (the variable is read here)
     yield c
     c.close()
+    if old is None:
+        del os.environ["SKYHIP_LINK_RESOLVE_MAX"]
+    else:
+        os.environ["SKYHIP_LINK_RESOLVE_MAX"] = old
 
 
 def test_decode_reference_and_own_frames(ctx, small_cases):
