@@ -172,6 +172,13 @@ int  skyhip_decompress_to_device(skyhip_ctx* ctx, int n, const uint8_t* const* i
                                  size_t* out_len, int32_t* status);
 int  skyhip_gather_md5(skyhip_ctx* ctx, int n, const uint64_t* run_prefix /* n+1 */, const uint64_t* run_src, const uint32_t* run_len,
                        uint8_t* const* out, const size_t* out_cap, size_t* out_len, uint8_t (*md5)[16]);
+/* MD5 of nseg byte ranges that are ALREADY in device memory (range k = len[k] < 32768 bytes at DEVICE address dev_addr[k]): fps[k] = its RFC 1321 digest.
+ * What the destination of a deduplicated transfer checks its newly arrived literal segments with -- every segment of a recipe carries its fingerprint,
+ * the segments are independent messages (one lane each, thousands at once), and a chunk whose literals all match and whose references name segments that
+ * matched when THEY arrived needs no serial whole-chunk chain on the batch's critical path (the reference's "# todo check hash",
+ * skyplane/gateway/operators/gateway_receiver.py:231; the whole-chunk digest still travels with the chunk for the object store's ContentMD5 check,
+ * gateway_operator.py:633-643). */
+int  skyhip_segment_md5_device(skyhip_ctx* ctx, size_t nseg, const uint64_t* dev_addr, const uint32_t* len, uint8_t (*fps)[16]);
 
 /* Forget every fingerprint in the dedup table. */
 int  skyhip_dedup_reset(skyhip_ctx* ctx);

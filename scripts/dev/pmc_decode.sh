@@ -11,7 +11,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     f = out / f"dec_{kind}_{name}_counter_collection.csv"
     per = {}
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name and r["Kernel_Name"].split("(")[0].split(".")[0] in ("sky_lz4f_scan", "sky_lz4_decode", "sky_lz4_parse", "sky_lz4_link", "sky_lz4_decode_seq"):
+        if r["Counter_Name"] == name and r["Kernel_Name"].split("(")[0].split(".")[0] in ("sky_lz4f_scan", "sky_lz4_decode", "sky_lz4_parse", "sky_lz4_link", "sky_lz4_decode_seq", "sky_lz4_resolve", "sky_lz4_chain"):
             k = r["Kernel_Name"].split("(")[0]
             per.setdefault(k, []).append(float(r["Counter_Value"]))
     tot[name] = {k: sum(v) / len(v) * 1024.0 for k, v in per.items()}      # KiB -> bytes, mean per launch
@@ -19,7 +19,7 @@ raw = n * 8 * 1024 * 1024
 entry = {"fetch_bytes_per_output_byte_raw_counter": round(sum(tot["FETCH_SIZE"].values()) / raw, 4), "write_bytes_per_output_byte": round(sum(tot["WRITE_SIZE"].values()) / raw, 4),
          "per_kernel_fetch": {k: round(v / raw, 4) for k, v in tot["FETCH_SIZE"].items()}, "per_kernel_write": {k: round(v / raw, 4) for k, v in tot["WRITE_SIZE"].items()}}
 entry["bytes_per_output_byte"] = round(entry["fetch_bytes_per_output_byte_raw_counter"] + entry["write_bytes_per_output_byte"], 4)
-entry["source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sky_lz4f_scan + sky_lz4_decode (+ parse / link), {n} frames of 8 MiB, kind {kind}; raw counters, per decoded "
+entry["source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sky_lz4f_scan + sky_lz4_decode (+ parse / link or resolve / chain), {n} frames of 8 MiB, kind {kind}; raw counters, per decoded "
                    "byte (the decoder's reads are 16-byte per-lane window loads and match-source gathers, not the wide coalesced stream read whose requests gfx950 tallies at half: no correction applied)")
 tf = Path(__file__).resolve().parent if False else Path(sys.argv[1])
 p = Path(__import__("os").environ.get("GRAFT_REPO_ROOT", "/root/repo")) / "profiles" / "traffic_decode.json"

@@ -15,7 +15,7 @@ EXPORTS = (
     "skyhip_last_hip_error", "skyhip_debug_prof", "skyhip_decompress_device", "skyhip_decompress_batch", "skyhip_decompress_ms",
     "skyhip_host_alloc", "skyhip_host_free", "skyhip_decompress_batch_md5", "skyhip_debug_fault", "skyhip_host_register", "skyhip_host_unregister",
     "skyhip_debug_guard_alloc", "skyhip_debug_guard_free", "skyhip_debug_guard_probe", "skyhip_dedup_literals",
-    "skyhip_dev_alloc", "skyhip_dev_free", "skyhip_decompress_to_device", "skyhip_gather_md5",
+    "skyhip_dev_alloc", "skyhip_dev_free", "skyhip_decompress_to_device", "skyhip_gather_md5", "skyhip_segment_md5_device",
 )
 
 
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
     lib.skyhip_decompress_to_device.restype = C.c_int
     lib.skyhip_gather_md5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.skyhip_gather_md5.restype = C.c_int
+    lib.skyhip_segment_md5_device.argtypes = [vp, C.c_size_t, vp, vp, vp]
+    lib.skyhip_segment_md5_device.restype = C.c_int
     lib.skyhip_get_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.skyhip_get_timing.restype = None
     lib.skyhip_reset_timing.argtypes = [vp]

@@ -297,6 +297,7 @@ struct skyhip_ctx {
     // host-batch staging (skyhip_process_batch): a whole group of chunks resident, copies on their own streams
     DevBuf<uint8_t> d_stage_in, d_stage_out, d_lit;
     DevBuf<sky_u64> d_run_src, d_run_dst; DevBuf<uint32_t> d_run_len;      // skyhip_gather_md5
+    DevBuf<sky_u64> d_sv_desc; DevBuf<uint8_t> d_sv_fps; DevBuf<uint32_t> d_sv_total;      // skyhip_segment_md5_device
     int stage_n = 0; size_t stage_in_stride = 0; std::vector<uint64_t> stage_len;      // the chunks skyhip_process_batch left in d_stage_in (skyhip_dedup_literals)
     hipStream_t s_up = nullptr, s_down = nullptr;
     std::vector<hipEvent_t> ev_up;    // upload-complete event per LZ4 sub-batch of a group (grow-only)
@@ -1086,6 +1087,43 @@ int skyhip_gather_md5(skyhip_ctx* c, int n, const uint64_t* run_prefix, const ui
     if (md5) rc = sky_process_impl(c, n, c->dec.d_stage_out.p, coff.data(), clen.data(), nullptr, nullptr, nullptr, nullptr, md5, SKYHIP_F_MD5, nullptr);
     HIPCHK(c, hipStreamSynchronize(c->s_down));
     return rc;
+#endif
+}
+
+int skyhip_segment_md5_device(skyhip_ctx* c, size_t nseg, const uint64_t* dev_addr, const uint32_t* len, uint8_t (*fps)[16]) {
+#ifndef SKY_WITH_CDC
+    (void)c; (void)nseg; (void)dev_addr; (void)len; (void)fps;
+    return SKYHIP_E_INVAL;
+#else
+    if (!c) return SKYHIP_E_INVAL;
+    if (nseg == 0) return SKYHIP_OK;
+    if (!dev_addr || !len || !fps) return SKYHIP_E_INVAL;
+    if (nseg > 0x7FFFFFFFull) return SKYHIP_E_TOOBIG;
+    HIPCHK(c, hipSetDevice(c->dev));
+    // the digest kernel of the CDC path (sky_segment_md5: a persistent grid deals a segment list to its lanes) over a list the CALLER made: a descriptor is
+    // (byte offset from `in`) << 15 | length, and with a null `in` the offset is the device address itself
+    std::vector<uint64_t> desc(nseg);
+    uint64_t bytes = 0;
+    for (size_t i = 0; i < nseg; i++) {
+        if (len[i] >= (1u << 15) || dev_addr[i] >= (1ull << 49) || (len[i] && !dev_addr[i])) return SKYHIP_E_INVAL;
+        desc[i] = (dev_addr[i] << 15) | len[i];
+        bytes += len[i];
+    }
+    HIPCHK(c, c->d_sv_desc.ensure(nseg)); HIPCHK(c, c->d_sv_fps.ensure(nseg * 16)); HIPCHK(c, c->d_sv_total.ensure(4));
+    const uint32_t total = (uint32_t)nseg;
+    HIPCHK(c, hipMemcpyAsync(c->d_sv_desc.p, desc.data(), nseg * 8, hipMemcpyHostToDevice, c->s_lz4));
+    HIPCHK(c, hipMemcpyAsync(c->d_sv_total.p, &total, 4, hipMemcpyHostToDevice, c->s_lz4));
+    SkySegMd5Args ma;
+    ma.in = nullptr; ma.desc = c->d_sv_desc.p; ma.seg_total = c->d_sv_total.p; ma.max_segs = total; ma.fps = c->d_sv_fps.p;
+    uint64_t waves = (nseg + 255u) / 256u;                       // (a range of at least 256 segments per wavefront, as in sky_cdc_run)
+    if (waves > c->cdc.segmd5_grid) waves = c->cdc.segmd5_grid;
+    if (waves < 1) waves = 1;
+    hipLaunchKernelGGL(sky_segment_md5, dim3((unsigned)waves), dim3(64), 0, c->s_lz4, ma);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fps, c->d_sv_fps.p, nseg * 16, hipMemcpyDeviceToHost, c->s_lz4));
+    HIPCHK(c, hipStreamSynchronize(c->s_lz4));                   // (desc and total live on this function's stack)
+    (void)bytes;
+    return SKYHIP_OK;
 #endif
 }
 

@@ -124,6 +124,8 @@ def parse_recipe(payload, max_raw_len: Optional[int] = None) -> Recipe:
     segs = np.frombuffer(mv, SEG_DTYPE, count=nseg, offset=HEADER_BYTES)
     if nseg and int(segs["kind"].max()) > KIND_REFERENCE:
         raise RecipeError("unknown segment kind")
+    if nseg and int(segs["len"].min()) == 0:
+        raise RecipeError("a segment of length zero (content-defined chunking never makes one)")      # (a literal segment without a literal stream)
     if int(segs["len"].astype(np.uint64).sum()) != raw_len:
         raise RecipeError("segment lengths do not add up to the chunk length")
     if int(segs["len"][segs["kind"] == KIND_LITERAL].astype(np.uint64).sum()) != lit_raw:
@@ -299,11 +301,13 @@ class DeviceSegmentStore(SegmentStore):
     lock the destination's lanes share).  Same bounds as SegmentStore (epochs kept per lane, byte budget, idle time); a group that goes takes its map
     and the buffers it kept alive (hip_ops.DeviceBuffer: the device memory is freed with the last of them) with it."""
 
-    def __init__(self, keep_epochs: int = 4, max_bytes: int = 32 << 30, **kwargs):
+    def __init__(self, keep_epochs: int = 4, max_bytes: int = 32 << 30, max_epoch_jump: Optional[int] = None, **kwargs):
         # (device memory is what this store spends: 288 GB of it, against the host RAM the other two stores live in.  Four epochs per lane: a source that
         # publishes batches while the next ones are on the device runs two epochs ahead of a destination that pays a digest chain per batch -- GPU call
         # r5u: with two epochs kept, chunks of epoch 0 were still queued when epoch 2 retired their literals)
-        super().__init__(keep_epochs=keep_epochs, max_bytes=max_bytes, **kwargs)
+        # (an epoch may arrive as far ahead of what this store has seen as it keeps epochs: with four epochs kept the source runs up to four ahead, and the
+        # inherited limit of two made a reordered batch a "lane jumps" error that stopped the worker -- ADVICE r5)
+        super().__init__(keep_epochs=keep_epochs, max_bytes=max_bytes, max_epoch_jump=max(2, keep_epochs) if max_epoch_jump is None else max_epoch_jump, **kwargs)
         from skyplane_amd import _hostlib
 
         self._h = _hostlib.load()
@@ -332,15 +336,31 @@ class DeviceSegmentStore(SegmentStore):
                 h = self._h.skyhost_map_new(14)
                 if not h:
                     raise MemoryError("skyhost_map_new")
-                m = self._maps[(lane, epoch)] = [h, []]
+                m = self._maps[(lane, epoch)] = [h, [], set()]     # native map, buffers kept alive, ids of the device blocks they are cut from
                 self._segs[(lane, epoch)] = {}               # (epochs_held / cleanup walk this dictionary's keys)
             new_bytes = C.c_uint64(0)
             if n:
                 if self._h.skyhost_map_put(m[0], n, fps.ctypes.data, addrs.ctypes.data, lens.ctypes.data, C.byref(new_bytes)) < 0:
                     raise MemoryError("skyhost_map_put")
+            # What the group PINS is what the budget counts: a batch's literal streams are cut from ONE device allocation (hip_ops._DeviceBlock),
+            # and the whole block stays until every group that kept a buffer from it is dropped -- the bytes of the new segments alone undercount it.
+            block = getattr(keep, "block", None)
+            if block is not None and getattr(block, "nbytes", 0):
+                if id(block) not in m[2]:
+                    m[2].add(id(block))
+                    self._b.nbytes[(lane, epoch)] += int(block.nbytes)
+            else:
+                self._b.nbytes[(lane, epoch)] += int(new_bytes.value)      # (a buffer that does not say what it is cut from: the new segments' bytes)
             m[1].append(keep)
-            self._b.nbytes[(lane, epoch)] += int(new_bytes.value)
             self._drop(self._b.over_budget((lane, epoch)))
+
+    def drop_not_live(self) -> int:
+        """Device memory ran out (SKYHIP_E_NOMEM): every group the sender can no longer reference goes, whatever the byte budget says.  Returns how many."""
+        with self._lock:
+            now = time.monotonic()
+            old = [k for k in self._maps if not self._b.is_live(k, now)]
+            self._drop(old)
+            return len(old)
 
     def get_arrays(self, lane: int, epoch: int, fps: np.ndarray):
         """(addrs [m] uint64, lens [m] uint32, misses, keep): address 0 = not there (yet).  `keep` holds the group's buffers: the caller keeps it until the

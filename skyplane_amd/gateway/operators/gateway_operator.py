@@ -84,11 +84,14 @@ class GatewayOperator(ABC):
 
             pool = self._tls.publish_pool = ThreadPoolExecutor(1, thread_name_prefix=f"{self.handle}-publish")
 
+        tries = self._tls.__dict__.setdefault("tries", {})      # (the LANE's back-off history: the helper thread has its own thread-local state)
+
         def defer(fn):
             def run():
                 try:
                     for cr, meta in zip(batch, fn()):
                         self.chunk_store.log_chunk_state(cr, ChunkState.complete, operator_handle=self.handle, worker_id=worker_id, metadata=meta)
+                        tries.pop(cr.chunk.chunk_id, None)      # as the synchronous path does: the dict must not grow with the transfer
                         if self.output_queue is not None:
                             self.output_queue.put(cr)
                 except Exception:
@@ -275,6 +278,17 @@ class GatewayHipCompress(GatewayOperator):
         sized for it -- and says so -- while the old one stays mapped until its published slots have been sent."""
         fb = ctx.frame_bound if hasattr(ctx, "frame_bound") else (lambda n: 15 + n + 4 * ((n + 65535) // 65536) + 4)
         w = getattr(self._tls, "writer", None)
+        # an arena this lane has outgrown goes -- mapping, page-lock and file -- as soon as the sender has sent (and deleted the pointer of) its last slot,
+        # not at worker exit (ADVICE r5)
+        still = []
+        for ow in getattr(self._tls, "old_writers", []):
+            if any(o is not None and o.exists() for o in ow._owner):
+                still.append(ow)
+            else:
+                shm_arena.forget(ow.arena)
+                ow.arena.close(unlink=True)
+        if hasattr(self._tls, "old_writers"):
+            self._tls.old_writers = still
         need = (fb(min(max(largest, 1 << 16), self.max_chunk_bytes)) + 4095) & ~4095
         if w is not None and (self.arena_slot_bytes or need <= w.arena.slot_bytes):
             return w
@@ -534,7 +548,12 @@ class GatewayHipCompress(GatewayOperator):
         # here), the decompressor's payloads come from the receiver's
         decomp = isinstance(self, GatewayHipDecompress)
         arena_side = "in" if decomp else "out"
-        for which in ("in", "out"):
+        names = ["in", "out"]
+        if self.dedup_wire and not decomp and getattr(self, "async_publish", False) and hasattr(ctx, "dedup_literals"):
+            # the deferred-publish path stages in two alternating sets (process_batch: "out" + parity, "lit" + parity): those are what the first batches
+            # would otherwise pin inside the timed path, and a plain "out" would stay pinned unused
+            names = ["in", "out0", "out1", "lit0", "lit1"]
+        for which in names:
             if self.handoff == "arena" and not self.dedup_wire and which == arena_side:
                 continue
             self._arena(ctx, which, per * self.max_batch)[::4096] = 0
@@ -648,9 +667,19 @@ class GatewayHipDecompress(GatewayHipCompress):
     GatewayHipCompress; there is no CPU fallback.
     """
 
-    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, dedup_store: str = "memory", out_slots: Optional[int] = None, **kwargs):
+    def __init__(self, *args, verify_md5: bool = True, dedup_wait_s: float = 60.0, dedup_store: str = "memory", out_slots: Optional[int] = None,
+                 dedup_verify: str = "segments", **kwargs):
         lanes_given, wait_given = kwargs.get("pipeline_depth") is not None, kwargs.get("fill_wait_s") is not None
         super().__init__(*args, **kwargs)
+        # How a chunk that travelled as a RECIPE is checked on the device path (round 6):
+        #   "segments": every literal segment that arrives is digested where it was decoded (skyhip_segment_md5_device: thousands of independent messages at
+        #       once, ~2.4 TB/s) and compared with the fingerprint its recipe carries; a reference names a segment that passed that test when IT arrived.  Every
+        #       byte of the rebuilt chunk is then covered by an MD5 that matched, and no batch pays a serial whole-chunk chain (82 ms per 8 MiB chunk, whatever
+        #       the batch holds: profiles/r5_dedup_wire.txt).  The sender's whole-chunk digest still travels with the request and is what the object store
+        #       checks on upload (ContentMD5, skyplane/gateway/operators/gateway_operator.py:633-643).
+        #   "chunk": round 5's rule -- the rebuilt chunk's own MD5 against Chunk.md5_hash, one chain per chunk and batch.
+        assert dedup_verify in ("segments", "chunk")
+        self.dedup_verify = dedup_verify
         # The base class's dedup rules are the SOURCE's (one lane: one fingerprint table; a short collect time for the lone lane).  A destination's lanes
         # share one segment store, and every one of its batches pays a whole-chunk digest chain whatever it holds: through the loopback a deduplicated
         # stream moves 18.9 Gbit/s with three lanes and 15.9 with two (profiles/r5_dedup_wire.txt), plain frames 44.0 with two and 38.1 with three.
@@ -724,10 +753,16 @@ class GatewayHipDecompress(GatewayHipCompress):
         src = np.zeros(nseg, np.uint64)
         keep = []
         if len(li):
+            if lit is None:
+                raise dedup_wire.RecipeError(f"chunk {cid}: literal segments without a literal stream")
             src[li] = np.uint64(lit.dptr) + lit_start[li]
             if cid not in self._put_done:
                 store.put_arrays(rec.lane, rec.epoch, fp[li], src[li], lens[li].astype(np.uint32), lit)
                 self._put_done.add(cid)
+        if store.over_budget_live and not getattr(self, "_warned_over_budget", False):
+            self._warned_over_budget = True      # said once: the budget never evicts what the sender may still reference, so the store outgrows it
+            print(f"[{self.handle}] device segment store holds more than its byte budget in LIVE (lane, epoch) groups (bounded by lanes x keep_epochs x the "
+                  "sender's dedup_epoch_bytes, counted as the device blocks they pin): raise the store's max_bytes or lower dedup_epoch_bytes", flush=True)
         if len(ri):
             addrs, hl, miss, keep = store.get_arrays(rec.lane, rec.epoch, fp[ri])
             if miss:
@@ -749,6 +784,34 @@ class GatewayHipDecompress(GatewayHipCompress):
         first = np.concatenate([[True], src[1:] != src[:-1] + lens[:-1]])
         starts = np.nonzero(first)[0]
         return src[starts], np.add.reduceat(lens, starts).astype(np.uint32), (lit, keep)      # (a run cannot exceed 32 bits: a chunk cannot -- max_chunk_bytes <= 1 GiB)
+
+    def _verify_literal_segments(self, ctx, chunk_reqs, todo, recipes, datas, cached):
+        """dedup_verify="segments": the literal segments of every recipe of the batch that is here for the first time -- ONE device call for all of them --
+        against the fingerprints their recipes carry.  A recipe that waited (its literal stream is in the lane's cache) was checked when it first came."""
+        addrs, lens, fps, owner = [], [], [], []
+        for j, rec in enumerate(recipes):
+            if rec is None or j in cached or not rec.lit_raw_len:
+                continue
+            lit = datas[j]
+            if lit is None or len(lit) != rec.lit_raw_len:
+                continue                               # (reported by the caller's length check)
+            segs = rec.segs
+            is_lit = segs["kind"] == dedup_wire.KIND_LITERAL
+            ln = segs["len"][is_lit].astype(np.uint64)
+            if not len(ln):
+                continue
+            if int(ln.max()) >= 1 << 15:
+                raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: a literal segment of {int(ln.max())} bytes (the CDC maximum is 16384)")
+            addrs.append(np.uint64(lit.dptr) + (np.cumsum(ln) - ln)); lens.append(ln.astype(np.uint32))
+            fps.append(np.ascontiguousarray(segs["fp"][is_lit]).reshape(-1, 16)); owner.append(np.full(len(ln), j))
+        if not addrs:
+            return
+        got = ctx.segment_md5_device(np.concatenate(addrs), np.concatenate(lens))
+        bad = np.nonzero((got != np.concatenate(fps)).any(axis=1))[0]
+        if len(bad):
+            j = int(np.concatenate(owner)[bad[0]])
+            raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: checksum mismatch, literal segment with md5 {got[bad[0]].tobytes().hex()} "
+                             f"!= the recipe's fingerprint {np.concatenate(fps)[bad[0]].tobytes().hex()} ({len(bad)} of {len(got)} segments of the batch differ)")
 
     def _rebuild(self, cid: str, rec: "dedup_wire.Recipe", lit, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """The chunk a recipe describes, or None while a referenced segment has not arrived.  lit = the decoded literal stream.  Runs of literal
@@ -891,8 +954,19 @@ class GatewayHipDecompress(GatewayHipCompress):
                 return None
             tag = f"{self.handle}_{os.getpid()}_{threading.get_ident() & 0xFFFFFF:x}"
             n_slots = max(2, min(self.out_slots, self.out_slot_bytes // size))      # (page-locked tmpfs: bounded in bytes too -- 64 MiB chunks get 16 slots per lane, not 64)
-            ls = shm_arena.LinkSlots(self.chunk_store.get_chunk_file_path("x").parent, tag, size, n_slots)
-            ls.register(ctx)
+            # "slower, never wrong" (ADVICE r5): no room for the slot files on the chunk tmpfs (ENOSPC from posix_fallocate) or a page-lock that fails
+            # (locked-memory limit) must not take the lane down -- the set is removed again, this lane stops asking, and its chunks take the write path
+            ls = None
+            try:
+                ls = shm_arena.LinkSlots(self.chunk_store.get_chunk_file_path("x").parent, tag, size, n_slots)
+                ls.register(ctx)
+            except (OSError, MemoryError, RuntimeError) as e:
+                if ls is not None:
+                    ls.close()
+                self.out_slots = 0
+                print(f"[{self.handle}] no page-locked slot files for decoded chunks ({n_slots} x {size} bytes: {type(e).__name__}: {e}): chunks are written "
+                      "through write() instead", flush=True)
+                return None
             self._tls.link_slots = ls
         return ls
 
@@ -933,7 +1007,19 @@ class GatewayHipDecompress(GatewayHipCompress):
             if "into" in kwargs:
                 kwargs["into"] = [into[j] for j in dec]
             if dec_dev:
-                for j, buf in zip(dec_dev, ctx.decompress_to_device([frames[j] for j in dec_dev], [raw_lens[j] for j in dec_dev])):
+                try:
+                    bufs = ctx.decompress_to_device([frames[j] for j in dec_dev], [raw_lens[j] for j in dec_dev])
+                except Exception as e:      # noqa: BLE001
+                    if getattr(e, "code", None) != -2:       # SKYHIP_E_NOMEM (include/skyhip.h)
+                        raise
+                    # device memory is what the segment store spends: let go of every group the sender can no longer reference and try once more
+                    import gc
+
+                    dropped = self._segment_store(on_device=True).drop_not_live()
+                    gc.collect()
+                    print(f"[{self.handle}] out of device memory for {len(dec_dev)} literal streams: dropped {dropped} retired segment groups, trying again", flush=True)
+                    bufs = ctx.decompress_to_device([frames[j] for j in dec_dev], [raw_lens[j] for j in dec_dev])
+                for j, buf in zip(dec_dev, bufs):
                     datas[j] = buf
             for j in range(len(todo)):
                 if recipes[j] is not None and j not in cached and not recipes[j].lit_raw_len:
@@ -953,8 +1039,12 @@ class GatewayHipDecompress(GatewayHipCompress):
         n_rec_bytes = sum((recipes[j].raw_len + 255) & ~255 for j in range(len(todo)) if recipes[j] is not None)
         reb_arena = self._arena(ctx, "rebuilt", n_rec_bytes) if (pinned and n_rec_bytes) else None
         reb_pos = 0
+        seg_verified = set()
         if on_device:
             gj, g_src, g_len, g_into, g_keep = [], [], [], [], []
+            by_segment = self.verify_md5 and self.dedup_verify == "segments" and hasattr(ctx, "segment_md5_device")
+            if by_segment:
+                self._verify_literal_segments(ctx, chunk_reqs, todo, recipes, datas, cached)
             for j, rec in enumerate(recipes):
                 if rec is None:
                     continue
@@ -962,6 +1052,8 @@ class GatewayHipDecompress(GatewayHipCompress):
                 if (0 if lit is None else len(lit)) != rec.lit_raw_len:
                     raise ValueError(f"[Gateway] chunk {chunk_reqs[todo[j]].chunk.chunk_id}: literal stream of {0 if lit is None else len(lit)} bytes, the recipe says {rec.lit_raw_len}")
                 cid_j = chunk_reqs[todo[j]].chunk.chunk_id
+                if by_segment:
+                    seg_verified.add(j)
                 try:
                     runs = self._rebuild_runs(cid_j, rec, lit)
                 except BaseException:
@@ -980,7 +1072,7 @@ class GatewayHipDecompress(GatewayHipCompress):
                     reb_pos += (rec.raw_len + 255) & ~255
                 gj.append(j); g_src.append(runs[0]); g_len.append(runs[1]); g_into.append(dstv); g_keep.append(runs[2])
             if gj:
-                outs, digs = ctx.gather_md5(g_src, g_len, g_into, want_md5=bool(want))
+                outs, digs = ctx.gather_md5(g_src, g_len, g_into, want_md5=bool(want) and not by_segment)
                 g_keep.clear()                         # the device has read every run: the buffers may go when their groups do
                 for k, j in enumerate(gj):
                     datas[j], digests[j] = outs[k], (digs[k] if digs is not None else None)
@@ -1028,6 +1120,8 @@ class GatewayHipDecompress(GatewayHipCompress):
             if len(data) != cr.chunk.chunk_length_bytes:
                 raise ValueError(f"[Gateway] chunk {cid}: {len(data)} bytes after decoding, expected {cr.chunk.chunk_length_bytes}")
             exp = self._expected_digest(cr) if self.verify_md5 else None
+            if j in seg_verified:
+                exp = None                             # checked segment by segment above (dedup_verify="segments")
             if exp is not None and dig != exp:
                 raise ValueError(f"[Gateway] chunk {cid}: checksum mismatch, md5 {dig.hex()} != {exp.hex()}")
             final = self.chunk_store.get_chunk_file_path(cid)
@@ -1049,6 +1143,8 @@ class GatewayHipDecompress(GatewayHipCompress):
                 meta["md5_hex"] = dig.hex()
             if recipes[j] is not None:
                 meta["dedup_reference_bytes"] = int(recipes[j].raw_len - recipes[j].lit_raw_len)
+                if j in seg_verified:
+                    meta["verified"] = "segment fingerprints"
             self._last_metadata[i] = meta
             oks[i] = True
         if trace:

@@ -94,7 +94,12 @@ def recv_chunks(conn: socket.socket, chunk_store: ChunkStore, decompress: Option
         data = decompress(bytes(payload), header.raw_data_len) if header.is_compressed else bytes(payload)
         if len(data) != header.raw_data_len:
             raise ValueError(f"[Gateway] chunk {header.chunk_id}: {len(data)} bytes after decoding, header says {header.raw_data_len}")
-        chunk_store.get_chunk_file_path(header.chunk_id).write_bytes(data)
+        # (temporary name + rename, never a truncating open of <id>.chunk: after a retransmission that name may be a hard link to one of gpu_decompress's
+        # page-locked slot files, and truncating it would free the pinned pages under the slot -- ADVICE r5)
+        final = chunk_store.get_chunk_file_path(header.chunk_id)
+        tmp = final.with_name(final.name + ".rawtmp")
+        tmp.write_bytes(data)
+        os.replace(tmp, final)
         received.append(header.chunk_id)
         if header.n_chunks_left_on_socket == 0:
             return received

@@ -313,26 +313,32 @@ class LinkSlots:
         self._next = 0
         self._lock = threading.Lock()
         self._registered_by = None
-        for k in range(self.n):
-            p = self.dir / f"_outslot_{tag}_{k}.bin"
-            fd = os.open(p, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o644)
-            try:
-                os.ftruncate(fd, self.size)
-                mm = mmap.mmap(fd, self.size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
-            finally:
-                os.close(fd)
-            self.paths.append(p)
-            self._maps.append(mm)
-            self.views.append(np.frombuffer(mm, np.uint8))
+        try:
+            for k in range(self.n):
+                p = self.dir / f"_outslot_{tag}_{k}.bin"
+                fd = os.open(p, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o644)
+                self.paths.append(p)                   # (from here on close() removes it)
+                try:
+                    # the blocks are ALLOCATED now: a sparse file on a full tmpfs raises SIGBUS at the first touch through the mapping --
+                    # the process dies -- where posix_fallocate raises ENOSPC, which the operator answers with the plain write path
+                    os.posix_fallocate(fd, 0, self.size)
+                    mm = mmap.mmap(fd, self.size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+                finally:
+                    os.close(fd)
+                self._maps.append(mm)
+                self.views.append(np.frombuffer(mm, np.uint8))
+        except BaseException:
+            self.close()                               # no slot file is left behind by a half-made set
+            raise
 
     def register(self, ctx) -> bool:
         """Page-lock every slot through ctx (once; a context without register_host -- emulator, null device -- needs none)."""
         if self._registered_by is not None or not hasattr(ctx, "register_host"):
             return False
+        self._registered_by = ctx              # (set first: close() after a failure half way unregisters what was registered; unregistering the rest fails quietly)
         for v in self.views:
-            v[::4096] = 0                      # touch: the pages exist before they are pinned
+            v[::4096] = 0                      # touch: the pages exist (posix_fallocate made sure they can) before they are pinned
             ctx.register_host(v)
-        self._registered_by = ctx
         return True
 
     def take(self, want: int) -> List[int]:
@@ -372,9 +378,17 @@ class LinkSlots:
         except FileNotFoundError:
             pass
         os.link(self.paths[slot], tmp)
-        os.replace(tmp, final)
-        with self._lock:
-            self._busy[slot] = False
+        try:
+            os.replace(tmp, final)
+        except BaseException:
+            try:
+                os.unlink(tmp)                 # (a .lnk left behind keeps the slot's link count at 2: the slot would never be free again)
+            except OSError:
+                pass
+            raise
+        finally:
+            with self._lock:
+                self._busy[slot] = False
 
     def give_back(self, slot: int):
         with self._lock:
@@ -382,16 +396,18 @@ class LinkSlots:
 
     def close(self):
         ctx, self._registered_by = self._registered_by, None
-        for v, mm, p in zip(self.views, self._maps, self.paths):
+        for v in self.views:
             if ctx is not None and hasattr(ctx, "unregister_host"):
                 try:
                     ctx.unregister_host(v)
                 except Exception:
                     pass
+        for p in self.paths:
             try:
                 p.unlink()                     # a published link keeps the inode (and its bytes) alive for whoever still reads it
             except FileNotFoundError:
                 pass
+        self.paths = []
         self.views = []
         for mm in self._maps:
             try:

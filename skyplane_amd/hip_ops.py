@@ -284,6 +284,18 @@ class SkyHipContext:
                                                 out_ptrs, out_cap, out_len, md5.ctypes.data if md5 is not None else None))
         return [into[i][: out_len[i]] for i in range(n)], ([md5[i].tobytes() for i in range(n)] if want_md5 else None)
 
+    def segment_md5_device(self, addrs, lens) -> np.ndarray:
+        """MD5 of byte ranges that are already in device memory (skyhip_segment_md5_device): addrs [n] uint64 DEVICE addresses, lens [n] uint32 (< 32768).
+        Returns [n, 16] uint8.  Thousands of independent messages at once: how a destination checks a recipe's literal segments against their fingerprints."""
+        addrs = np.ascontiguousarray(addrs, np.uint64)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        n = int(lens.size)
+        assert addrs.size == n
+        fps = np.zeros((n, 16), np.uint8)
+        if n:
+            self._check(self._lib.skyhip_segment_md5_device(self._h, n, addrs.ctypes.data, lens.ctypes.data, fps.ctypes.data))
+        return fps
+
     def decompress_device(self, d_in: int, in_off, in_len, d_out: int, out_off, out_cap):
         n = int(len(in_off))
         in_off = np.ascontiguousarray(in_off, np.uint64); in_len = np.ascontiguousarray(in_len, np.uint64)

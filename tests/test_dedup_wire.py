@@ -359,7 +359,7 @@ class DeviceStoreEmuContext(ArenaEmuDedupContext):
 
     def __init__(self):
         super().__init__()
-        self.gathers = 0
+        self.gathers = self.chains = self.segment_calls = 0
 
     def decompress_to_device(self, frames, raw_lens):
         return [_HostBuf(np.frombuffer(o, np.uint8).copy()) for o in ArenaEmuDedupContext.decompress_batch(self, frames, raw_lens)]
@@ -374,7 +374,14 @@ class DeviceStoreEmuContext(ArenaEmuDedupContext):
             outs.append(dst[:len(blob)])
             digs.append(hashlib.md5(blob).digest())
         self.gathers += 1
+        self.chains += len(into) if want_md5 else 0
         return outs, (digs if want_md5 else None)
+
+    def segment_md5_device(self, addrs, lens):
+        import ctypes
+
+        self.segment_calls += 1
+        return np.frombuffer(b"".join(hashlib.md5(ctypes.string_at(int(a), int(n))).digest() for a, n in zip(addrs, lens)), np.uint8).reshape(-1, 16).copy()
 
 
 def test_recipes_are_put_together_from_device_resident_runs(tmp_path):
@@ -404,6 +411,57 @@ def test_recipes_are_put_together_from_device_resident_runs(tmp_path):
     slot_inodes = {f.stat().st_ino for f in (tmp_path / "dst").glob("_outslot_*")}
     assert slot_inodes and any(dst.get_chunk_file_path(cr.chunk.chunk_id).stat().st_ino in slot_inodes for cr in reqs)
     dec.worker_exit(0)
+
+
+def test_recipes_are_verified_segment_by_segment_not_by_a_chain(tmp_path):
+    """dedup_verify="segments" (the default, round 6): a batch of recipes costs ONE call that digests its newly arrived literal segments and no whole-chunk
+    chain; a literal stream that does not match its recipe's fingerprints is a checksum mismatch; dedup_verify="chunk" is round 5's rule."""
+    chunks = _dup_chunks(n=5, size=512 << 10)
+    for mode in ("segments", "chunk"):
+        src, dst, reqs = _stores(tmp_path / mode, chunks)
+        for cr, c in zip(reqs, chunks):
+            cr.chunk.md5_hash = hashlib.md5(c).hexdigest()
+        dctx = DeviceStoreEmuContext()
+        comp, dec = _ops(src, dst, ArenaEmuDedupContext(), dctx)
+        dec.dedup_verify = mode
+        assert all(comp.process_batch(reqs))
+        _ship(src, dst, reqs)
+        assert all(dec.process_batch(reqs))
+        if mode == "segments":
+            assert dctx.segment_calls == 1 and dctx.chains == 0
+            assert all(m.get("verified") == "segment fingerprints" for m in dec._last_metadata)
+        else:
+            assert dctx.segment_calls == 0 and dctx.chains == len(reqs)
+        for cr, c in zip(reqs, chunks):
+            assert dst.get_chunk_file_path(cr.chunk.chunk_id).read_bytes() == c
+        dec.worker_exit(0)
+    # one literal byte wrong on the wire: the frame still decodes (LZ4 frames carry no checksum here), the segment's fingerprint does not match
+    src, dst, reqs = _stores(tmp_path / "bad", chunks)
+    dctx = DeviceStoreEmuContext()
+    comp, dec = _ops(src, dst, ArenaEmuDedupContext(), dctx)
+    assert all(comp.process_batch(reqs))
+    _ship(src, dst, reqs)
+    real = dctx.decompress_to_device
+
+    def flipped(frames, raw_lens):
+        bufs = real(frames, raw_lens)
+        bufs[0].arr[len(bufs[0]) // 2] ^= 0x40
+        return bufs
+
+    dctx.decompress_to_device = flipped
+    with pytest.raises(ValueError, match="checksum mismatch, literal segment"):
+        dec.process_batch(reqs)
+    dec.worker_exit(0)
+
+
+def test_recipe_with_a_zero_length_segment_is_refused():
+    segs = np.zeros(2, dedup_wire.SEG_DTYPE)
+    segs["len"] = [0, 10]
+    head = dedup_wire._HDR.pack(dedup_wire.MAGIC, dedup_wire.VERSION, 1, 0, 2, 10, 0, 0) + segs.tobytes()
+    segs["kind"] = [0, 1]
+    with pytest.raises(dedup_wire.RecipeError, match="length zero"):
+        dedup_wire.parse_recipe(dedup_wire._HDR.pack(dedup_wire.MAGIC, dedup_wire.VERSION, 1, 0, 2, 10, 0, 0) + segs.tobytes())
+    assert head
 
 
 def test_file_segment_store_is_shared_between_processes(tmp_path):
@@ -650,6 +708,24 @@ def test_native_fingerprint_map_and_device_store_bounds():
     assert st.epochs_held(7) == [1, 2] and ref0() is None and st.get_arrays(7, 0, fps[:4])[2] == 4
     st.cleanup()
     assert st.bytes_held == 0 and not st._maps
+    # what a group PINS is what the budget counts: buffers cut from one device block hold the whole block, once per group
+    class Block:
+        nbytes = 1 << 20
+
+    blk = Block()
+    cut1, cut2 = Buf(), Buf()
+    cut1.block = cut2.block = blk
+    st.put_arrays(9, 0, fps[:3], addrs[:3], lens[:3], cut1)
+    st.put_arrays(9, 0, fps[3:6], addrs[3:6], lens[3:6], cut2)
+    assert st.bytes_held == 1 << 20
+    st.put_arrays(9, 1, fps[6:7], addrs[6:7], lens[6:7], cut2)       # another group keeps a piece of the same block: it pins it too
+    assert st.bytes_held == 2 << 20
+    # an epoch as far ahead as the store keeps epochs is a reordered batch, not an attack (keep_epochs=2 -> jump of 2 is fine, 3 is refused)
+    st.put_arrays(9, 3, fps[7:8], addrs[7:8], lens[7:8], Buf())
+    with pytest.raises(dedup_wire.RecipeError, match="jumps"):
+        st.put_arrays(9, 7, fps[8:9], addrs[8:9], lens[8:9], Buf())
+    assert st.drop_not_live() == 0 and dedup_wire.DeviceSegmentStore()._b.max_epoch_jump == 4
+    st.cleanup()
 
 
 class DeviceSourceEmuContext(ArenaEmuDedupContext):

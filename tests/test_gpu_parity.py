@@ -496,3 +496,59 @@ def test_device_resident_literal_streams_and_gathered_chunks(ctx):
     assert outs[0].tobytes() == streams[1] + streams[0][5:1005] and digs[0] == hashlib.md5(streams[1] + streams[0][5:1005]).digest()
     del tb, bufs
     other.close()
+
+
+def test_segment_md5_of_device_resident_ranges(ctx):
+    """skyhip_segment_md5_device (round 6): the digests of thousands of byte ranges that are already in device memory -- every residue of the RFC 1321
+    padding, lengths 0 .. 32767, any alignment -- equal hashlib's; what gpu_decompress checks a recipe's literal segments with."""
+    stream = synth.silesia_like(3 << 20, config_id=5, seg_min=3000, seg_max=40000).tobytes()
+    (buf,) = ctx.decompress_to_device([ref.lz4f_compress(stream)], [len(stream)])
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([np.arange(0, 200), [16384, 16383, 32767, 1024, 4096], rng.integers(1, 16385, 3000)]).astype(np.uint32)
+    offs = rng.integers(0, len(stream) - 32768, lens.size).astype(np.uint64)
+    got = ctx.segment_md5_device(np.uint64(buf.dptr) + offs, lens)
+    for o, n, g in zip(offs, lens, got):
+        assert g.tobytes() == hashlib.md5(stream[int(o):int(o) + int(n)]).digest(), (int(o), int(n))
+    from skyplane_amd import hip_ops
+
+    with pytest.raises(hip_ops.SkyHipError):
+        ctx.segment_md5_device(np.array([buf.dptr], np.uint64), np.array([32768], np.uint32))      # a length the descriptor cannot hold
+
+
+def test_device_segment_store_keeps_what_a_gather_still_reads(ctx):
+    """Regression for GPU call r5t (round 5: a memory access fault at 1024 chunks): the device segment store resolves fingerprints to ADDRESSES; another lane
+    then moves the group's lane past keep_epochs, the group is dropped and -- without an owner on the reader's side -- its device memory is freed (and handed
+    out again) before the gather has read it.  get_arrays returns the group's buffers; while the caller holds them the bytes stay what they were."""
+    import gc
+
+    from skyplane_amd.gateway import dedup_wire
+
+    store = dedup_wire.DeviceSegmentStore(keep_epochs=2, max_bytes=1 << 30)
+    stream = synth.gen_text(synth.rng_for(4, 1), 4 << 20).tobytes()
+    seg = 8192
+    n = len(stream) // seg
+    fps = np.frombuffer(b"".join(hashlib.md5(stream[k * seg:(k + 1) * seg]).digest() for k in range(n)), np.uint8).reshape(n, 16)
+    (buf,) = ctx.decompress_to_device([ref.lz4f_compress(stream)], [len(stream)])
+    store.put_arrays(7, 0, fps, np.uint64(buf.dptr) + np.arange(n, dtype=np.uint64) * seg, np.full(n, seg, np.uint32), buf)
+    first_ptr = buf.dptr
+    del buf
+    addrs, lens, miss, keep = store.get_arrays(7, 0, fps)      # lane A resolved its references ...
+    assert miss == 0 and keep
+    other = bytes(len(stream))
+    junk = []
+    for epoch in (1, 2, 3):                                     # ... lane B carries the sender's lane three epochs on: epoch 0 is retired
+        (b2,) = ctx.decompress_to_device([ref.lz4f_compress(other)], [len(other)])
+        store.put_arrays(7, epoch, fps[:1], np.array([b2.dptr], np.uint64), np.array([seg], np.uint32), b2)
+        junk.append(b2)
+    gc.collect()
+    assert store.epochs_held(7) == [2, 3]
+    for _ in range(8):                                          # memory the allocator would hand out again if epoch 0's block had been freed
+        (b3,) = ctx.decompress_to_device([ref.lz4f_compress(other)], [len(other)])
+        junk.append(b3)
+    assert all(j.dptr != first_ptr for j in junk)
+    outs, digs = ctx.gather_md5([addrs], [lens], [np.empty(len(stream), np.uint8)])
+    assert digs[0] == hashlib.md5(stream).digest() and outs[0].tobytes() == stream
+    got = ctx.segment_md5_device(addrs, lens)
+    assert (got == fps).all()
+    del keep, junk
+    store.cleanup()
