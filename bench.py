@@ -633,6 +633,12 @@ def main():
                         "the steps in flight"}
         # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (scripts/pmc.sh); a committed measurement is
         # quoted only for the kernel and stream it was taken on
+        # which unit of the CU the dominant kernel keeps busy (it is not HBM): the committed SQ-counter summary of the shipping kernel, quoted
+        bf = ROOT / "profiles" / "binding.json"
+        if bf.exists() and not emu:
+            bnd = json.loads(bf.read_text()).get(kname)
+            if bnd:
+                res["roofline"]["binding"] = {**bnd, "quoted": True}
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             t = json.loads(tf.read_text()).get(f"{kname}:{'cdc' if args.cdc else stream}")

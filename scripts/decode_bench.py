@@ -73,7 +73,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(wall * 1e3, 3), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n} LZ4 frames of 8 MiB chunks of the Silesia-like stream resident in HBM, 16 distinct", "frames": a.kind, "frame_bytes": comp,
                        "lz4_ratio": round(raw / comp, 4)},
-            "roofline": {"bound": "hbm", "kernel": "sky_lz4f_scan + sky_lz4_decode" + (" + sky_lz4_parse + sky_lz4_link" if a.kind == "linked" else ""),
+            "roofline": {"bound": "hbm", "kernel": "sky_lz4f_scan + " + ("sky_lz4_decode" if a.kind != "linked" else
+                                                                    "sky_lz4_parse + " + ("sky_lz4_resolve + sky_lz4_chain" if n <= int(os.environ.get("SKYHIP_LINK_RESOLVE_MAX", "192")) else "sky_lz4_link")),
                          "achieved": round((raw + comp) / kern / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round((raw + comp) / kern / 8e12, 5), "traffic": None,
                          "launch_ms": round(kern * 1e3, 3), "algorithmic_bytes_per_launch": raw + comp},
             "verified": {"outputs_equal_chunks": ok, "checked": min(n, 16)}}
