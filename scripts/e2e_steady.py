@@ -148,6 +148,14 @@ def main():
     ap.add_argument("--dst-fill-wait-ms", type=float, default=-1, help="destination lanes collect for up to this long before a device call (-1 = the operator's default)")
     ap.add_argument("--dst-depth", type=int, default=0, help="pipeline lanes per destination worker (0 = the operator's default)")
     ap.add_argument("--src-depth", type=int, default=0, help="pipeline lanes per source worker (0 = the operator's default)")
+    ap.add_argument("--src-reader", choices=["none", "files", "slots"], default="none", help="stand in for read_object_store INSIDE the timed region (none = the chunk "
+                    "files exist before the clock starts, as in rounds 2-5): four reader threads write every chunk's bytes -- 'files': open(path, \"wb\") as "
+                    "download_object does today; 'slots': INTEGRATION 6e -- the name is first linked to one of gpu_compress's page-locked source slots "
+                    "(shm_arena.claim_slot) and the bytes are written into the existing file -- and the sender's side deletes <id>.chunk when it is sent "
+                    "(the daemon's clean-up, gateway_daemon_api.py:125-127), which frees the slot")
+    ap.add_argument("--in-slots", type=int, default=256, help="--src-reader slots: source slot files per source worker")
+    ap.add_argument("--dedup-verify", choices=["segments", "chunk"], default="segments", help="--dedup-wire: how the destination checks a rebuilt chunk -- its newly "
+                    "arrived literal segments against their fingerprints (one parallel device call per batch, the operator's default) or its own whole-chunk MD5 chain")
     a = ap.parse_args()
     if a.dedup_wire:
         os.environ["E2E_DEDUP_WIRE"] = "1"
@@ -177,8 +185,18 @@ def main():
         # thousand-odd files (60-80 s around a 2 s measurement, NOTES.md), which is what kept the runs too short for their pipeline fill and drain not to show.
         proto = {}
 
-        def make(i):
+        reader_jobs = {}                                  # --src-reader: chunk id -> the bytes its reader thread will write
+
+        def make(i, late=False):
             cid = uuid.uuid4().hex
+            if late and dd_stream is None:
+                k = i % 4
+                if k not in proto:
+                    data = base[k].tobytes()
+                    proto[k] = (data, hashlib.md5(data).digest())
+                reader_jobs[cid] = proto[k][0]
+                digests[cid] = proto[k][1]
+                return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
             if dd_stream is None:
                 k = i % 4
                 if k not in proto:
@@ -195,8 +213,10 @@ def main():
                 digests[cid] = hashlib.md5(data).digest()
             return ChunkRequest(chunk=Chunk(src_key=f"/s/{i}", dest_key=str(i), chunk_id=cid, chunk_length_bytes=size, partition_id="0"))
 
-        warm = [make(i) for i in range(K)]              # one per connection
-        main_reqs = [make(K + i) for i in range(a.chunks)]
+        late = a.src_reader != "none"
+        assert not (late and a.dedup_wire), "--src-reader is for the plain-frame stream"
+        warm = [make(i, late) for i in range(K)]              # one per connection
+        main_reqs = [make(K + i, late) for i in range(a.chunks)]
         shares = [[warm[k]] + main_reqs[k::K] for k in range(K)]
         port_q, done_q = Queue(), Queue()
         rx = Process(target=receiver_main, args=(dst, port_q, done_q, K, (max(2, a.dst_depth or 3) * a.max_batch * max(a.workers, 1) + K) if a.handoff == "arena" else 0, size))
@@ -207,10 +227,12 @@ def main():
         kw["prealloc"] = not a.no_prealloc
         op = GatewayHipCompress("gpu_compress_0", "local:e2e", q_in, q_out, err_ev, err_q, src, n_processes=a.workers, max_batch=a.max_batch,
                                 max_chunk_bytes=size, device_ids=[0], dedup_wire=a.dedup_wire, handoff=a.handoff, pipeline_depth=a.src_depth or None,
-                                dedup_epoch_bytes=a.dedup_epoch_mb << 20, **kw)
+                                dedup_epoch_bytes=a.dedup_epoch_mb << 20, in_slots=a.in_slots if a.src_reader == "slots" else 0,
+                                in_slot_chunk_bytes=size if a.src_reader == "slots" else 0, **kw)
         dop = GatewayHipDecompress("gpu_decompress_0", "local:e2e-dst", dq_in, dq_out, err_ev, err_q, dst_store, n_processes=1 if (a.dedup_wire and a.dedup_store == "memory") else a.workers,
                                    max_batch=a.max_batch, max_chunk_bytes=size, device_ids=[0], dedup_store=a.dedup_store, pipeline_depth=a.dst_depth or None,
                                    dedup_wire=a.dedup_wire,      # (what the planner patch passes: INTEGRATION 10 -- three lanes by default then)
+                                   dedup_verify=a.dedup_verify,
                                    out_slots=None if a.out_slots < 0 else a.out_slots, fill_wait_s=None if a.dst_fill_wait_ms < 0 else a.dst_fill_wait_ms / 1e3, **kw)
         total = K + a.chunks
         ready, ready_cv = {}, threading.Condition()
@@ -254,6 +276,11 @@ def main():
                     dig = hip_sender.chunk_digest(src, cr.chunk.chunk_id)
                     dst_store.add_chunk_request(ChunkRequest(chunk=dataclasses.replace(cr.chunk, md5_hash=dig.hex() if dig else None)))
                     n_sent = hip_sender.send_chunk(sock, src, cr, n_chunks_left_on_socket=len(shares[k]) - idx - 1, release=True)
+                    if late:                            # the daemon's unlink of a completed chunk: what hands a source slot back
+                        try:
+                            os.unlink(src.get_chunk_file_path(cr.chunk.chunk_id))
+                        except FileNotFoundError:
+                            pass
                     if idx:
                         wire[k] += n_sent
                     trace["sent"].append(time.perf_counter())
@@ -289,8 +316,26 @@ def main():
                     consumers.submit(consume, cr, do_hash)
             return got
 
+        slot_claims = {"slots": 0, "files": 0}
+
+        def read_and_queue(cr):                        # GatewayObjStoreReadOperator.process + download_object for one chunk, then on to gpu_compress
+            from skyplane_amd.gateway import shm_arena
+            path = src.get_chunk_file_path(cr.chunk.chunk_id)
+            data = reader_jobs[cr.chunk.chunk_id]
+            claimed = a.src_reader == "slots" and shm_arena.claim_slot(path, len(data))
+            slot_claims["slots" if claimed else "files"] += 1
+            with open(path, "r+b" if claimed else "wb") as f:
+                f.write(data)
+            src.add_chunk_request(cr)
+
+        readers = ThreadPoolExecutor(4) if late else None
+
         op.start_workers()
         dop.start_workers()
+        if a.src_reader == "slots":                    # the source's slots are made when its lanes start: the first download finds them
+            t_w = time.time()
+            while time.time() - t_w < 120 and not list(Path(src.get_chunk_file_path("x")).parent.glob("_inslot_*.bin")):
+                time.sleep(0.05)
         drainer = threading.Thread(target=drain_status)
         drainer.start()
         threads = [threading.Thread(target=collect)] + [threading.Thread(target=send, args=(k,)) for k in range(K)]
@@ -298,13 +343,19 @@ def main():
             t.start()
         t_cold = time.perf_counter()
         for cr in warm:
-            src.add_chunk_request(cr)
+            if late:
+                readers.submit(read_and_queue, cr)
+            else:
+                src.add_chunk_request(cr)
         assert wait_decoded(K) == K or err_ev.is_set()
         warm_s = time.perf_counter() - t_cold
         t0 = time.perf_counter()
         go.set()
         for cr in main_reqs:
-            src.add_chunk_request(cr)
+            if late:
+                readers.submit(read_and_queue, cr)
+            else:
+                src.add_chunk_request(cr)
         n_dec = wait_decoded(a.chunks)
         if consumers is not None:
             consumers.shutdown(wait=True)              # the clock stops when the last chunk has been checked and deleted
@@ -349,7 +400,7 @@ def main():
                 if ts:
                     print(f"trace {name:10s} n={len(ts)} first={ts[0]:.3f}s median={ts[len(ts) // 2]:.3f}s last={ts[-1]:.3f}s", file=sys.stderr)
         print(json.dumps({"e2e": "loopback, steady state", "context": a.context, "chunks": a.chunks, "chunk_bytes": size, "connections": K, "workers": a.workers,
-                          "max_batch": a.max_batch, "src_depth": a.src_depth or None, "dst_depth": a.dst_depth or None, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
+                          "max_batch": a.max_batch, "src_depth": a.src_depth or None, "dst_depth": a.dst_depth or None, "prealloc": not a.no_prealloc, "handoff": a.handoff, "dedup_wire": a.dedup_wire, "dedup_store": a.dedup_store if a.dedup_wire else None, "dedup_verify": a.dedup_verify if a.dedup_wire else None, "src_reader": a.src_reader, "src_reader_writes": slot_claims if late else None, "effective_gbit_s": round(raw * 8 / elapsed / 1e9, 3), "middle_half_gbit_s": steady, "seconds": round(elapsed, 3),
                           "warmup_seconds": round(warm_s, 3), "raw_GiB": round(raw / 2**30, 3), "wire_ratio": round(raw / max(sum(wire), 1), 3),
                           "status_records": len(status_records), "verified": a.context != "null",
                           "dst_consume": ({"chunks_deleted_on_arrival": consumed["n"], "hashed_on_the_cpu": consumed["hashed"]} if a.dst_consume else None),

@@ -174,8 +174,20 @@ class GatewayHipCompress(GatewayOperator):
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: Optional[float] = None,
                  prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0,
-                 arena_slot_bytes: int = 0):
+                 arena_slot_bytes: int = 0, in_slots: int = 0, in_slot_chunk_bytes: int = 0):
         super().__init__(handle, region, input_queue, output_queue, error_event, error_queue, chunk_store, n_processes)
+        # The RAW side of the source (round 6, SURVEY 8f item 2 "and the reader's file write"): `in_slots` page-locked slot files per worker process
+        # (shm_arena.InSlots) that the reader -- GatewayObjStoreReadOperator with INTEGRATION 6e's two lines -- links ``<id>.chunk`` to BEFORE it downloads,
+        # so that the chunk's bytes land in pinned memory and this operator hands them to the device where they lie.  0 = off (the default: it needs the
+        # reader-side patch; a chunk file that is not a slot link is read as before, so turning it on without the patch costs only the pinned memory).
+        # `in_slot_chunk_bytes`: the transfer's chunk size when it is known up front (then the slots exist before the first download), 0 = the first
+        # batch's usual chunk length.  At most `in_slot_bytes` of slots per worker.
+        self.in_slots = int(in_slots)
+        self.in_slot_chunk_bytes = int(in_slot_chunk_bytes)
+        self.in_slot_bytes = 4 << 30
+        self._in_slot_set = None               # (per worker process, shared by its lanes)
+        self._in_slot_failed = False
+        self._in_slots_lock = threading.Lock()
         # How a frame reaches the sender.  "arena": the device writes it by DMA into a slot of a shared, page-locked arena file in
         # the chunk directory and `<id>.chunk.lz4f` is a pointer to the slot (gateway/shm_arena.py) -- the sender sendfile()s it from there and unlinks
         # the pointer, which frees the slot.  "files": one payload file per chunk, as in rounds 1-2 (also what a chunk falls back to when every slot
@@ -306,21 +318,64 @@ class GatewayHipCompress(GatewayOperator):
         self._tls.writer, self._tls.writer_gen = w, gen + 1
         return w
 
+    def _in_slots(self, ctx, sizes) -> Optional["shm_arena.InSlots"]:
+        """This WORKER's source slot files (made by its first lane that gets here; page-locked once per process, which is what every lane's context of the
+        process may DMA from).  Sized by `in_slot_chunk_bytes` -- the transfer's chunk size, which the planner knows -- or, when that was left
+        at 0, by the first batch's usual chunk length: the reader can only use them for the chunks it downloads AFTER they exist."""
+        if self.in_slots <= 0:
+            return None
+        with self._in_slots_lock:
+            if self._in_slot_set is None and not self._in_slot_failed:
+                lens_sorted = sorted(s for s in sizes if s > 0)
+                size = self.in_slot_chunk_bytes or (max(set(lens_sorted), key=lens_sorted.count) if lens_sorted else 0)
+                if size <= 0:
+                    return None
+                n = max(2, min(self.in_slots, self.in_slot_bytes // size))
+                ins = None
+                try:
+                    ins = shm_arena.InSlots(self.chunk_store.get_chunk_file_path("x").parent, f"{self.handle}_{os.getpid()}", size, n)
+                    ins.register(ctx)
+                    self._in_slot_set = ins
+                except (OSError, MemoryError, RuntimeError) as e:
+                    if ins is not None:
+                        ins.close()
+                    self._in_slot_failed = True
+                    print(f"[{self.handle}] no page-locked source slots ({n} x {size} bytes: {type(e).__name__}: {e}): chunk files are read as before", flush=True)
+            return self._in_slot_set
+
     def _read_chunks(self, chunk_reqs: List[ChunkRequest], ctx):
         """Raw bytes of every request.  With a real context: views of the pinned arena filled by readinto (zero-copy
         hand-off); otherwise plain bytes, as the reference reads them at gateway_operator.py:350-351."""
         sizes = [int(cr.chunk.chunk_length_bytes) for cr in chunk_reqs]
         pinned = hasattr(ctx, "pinned_buffer")
         arena, pos, datas = None, 0, []
+        # Round 6: a chunk file that is a hard link to one of this worker's page-locked source slots (shm_arena.InSlots: the reader wrote the chunk INTO
+        # pinned memory, INTEGRATION 6e) is handed to the device where it lies -- no read, no copy.  Everything else is read into pinned staging as before.
+        ins = self._in_slots(ctx, sizes)
+        slot_views = [None] * len(chunk_reqs)
+        if ins is not None:
+            for j, (cr, size) in enumerate(zip(chunk_reqs, sizes)):
+                try:
+                    st = os.stat(self.chunk_store.get_chunk_file_path(cr.chunk.chunk_id))
+                except FileNotFoundError:
+                    continue
+                if st.st_nlink >= 2:
+                    slot_views[j] = ins.view_of(st, size)
         if pinned:
-            arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s in sizes))
+            arena = self._arena(ctx, "in", sum((s + 255) & ~255 for s, v in zip(sizes, slot_views) if v is None) or 1)
         jobs = []
-        for cr, size in zip(chunk_reqs, sizes):
-            jobs.append((cr, size, arena[pos:pos + size] if pinned else None))
+        for cr, size, sv in zip(chunk_reqs, sizes, slot_views):
+            if sv is not None:
+                jobs.append((cr, size, sv, True))
+                continue
+            jobs.append((cr, size, arena[pos:pos + size] if pinned else None, False))
             pos += (size + 255) & ~255
+        self._tls.__dict__["in_slot_hits"] = self._tls.__dict__.get("in_slot_hits", 0) + sum(v is not None for v in slot_views)
 
         def read_one(job):
-            cr, size, data = job
+            cr, size, data, in_place = job
+            if in_place:
+                return data[:size]
             path = self.chunk_store.get_chunk_file_path(cr.chunk.chunk_id)
             with open(path, "rb") as f:
                 if data is None:
@@ -560,11 +615,15 @@ class GatewayHipCompress(GatewayOperator):
         if self.handoff == "arena" and not self.dedup_wire and not decomp:
             self._writer(ctx, self.max_chunk_bytes)      # prealloc: the configured maximum sizes the slots
 
+
     def _lane_loop(self, worker_id: int):
         """One pipeline lane: drain up to max_batch requests, one device call, hand the chunks on."""
-        if self.prealloc:
+        if self.prealloc or (self.in_slots > 0 and self.in_slot_chunk_bytes > 0):
             try:
-                self._prealloc()
+                if not isinstance(self, GatewayHipDecompress) and self.in_slots > 0 and self.in_slot_chunk_bytes > 0:
+                    self._in_slots(self._context(), [self.in_slot_chunk_bytes])      # the reader can claim a slot for the very first chunk
+                if self.prealloc:
+                    self._prealloc()
             except Exception:
                 self.error_queue.put(traceback.format_exc())
                 self.error_event.set()
@@ -621,6 +680,9 @@ class GatewayHipCompress(GatewayOperator):
 
     def process_exit(self, worker_id: int):
         """Every lane of this worker process has left its loop."""
+        ins, self._in_slot_set = self._in_slot_set, None
+        if ins is not None:
+            ins.close()
 
     def worker_exit(self, worker_id: int):
         for w in [getattr(self._tls, "writer", None)] + list(getattr(self._tls, "old_writers", [])):
@@ -720,6 +782,7 @@ class GatewayHipDecompress(GatewayHipCompress):
             return self._store
 
     def process_exit(self, worker_id: int):
+        super().process_exit(worker_id)
         if self._store is not None:            # the transfer is over for this process: what its segment store holds (RAM, or files in the chunk directory) goes
             self._store.cleanup()
             self._store = None

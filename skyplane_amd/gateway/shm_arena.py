@@ -415,3 +415,130 @@ class LinkSlots:
             except (BufferError, ValueError):
                 pass
         self._maps = []
+
+
+# ---- source, raw side: the READER's file write lands in page-locked memory (round 6, SURVEY 8f item 2 "and the reader's file write") ----
+IN_PREFIX = "_inslot_"
+
+
+class InSlots:
+    """Files of exactly `size` bytes in the SOURCE gateway's chunk directory, made, mapped MAP_SHARED and page-locked by gpu_compress's worker -- the mirror
+    image of LinkSlots.  Here the operator is the CONSUMER: whoever writes ``<id>.chunk`` (the reference's GatewayObjStoreReadOperator through
+    ``download_object``, gateway_operator.py:555-575) first makes that name a hard link to a free slot (``claim_slot`` below: one call in the reader,
+    INTEGRATION.md 6e) and then writes the chunk's bytes into the EXISTING file -- which needs the object-store interfaces to open an existing destination
+    without truncating it (``"r+b"`` instead of ``"wb"``: s3_interface.py:183, posix_file_interface.py:105,109 and their siblings; a truncation would free
+    the pinned pages).  gpu_compress then finds that ``<id>.chunk``'s inode is one of its slots and hands the device the mapped, page-locked bytes: the
+    page cache -> staging copy of `_read_chunks` (one read of every chunk by the CPU) is gone.  The daemon deleting ``<id>.chunk`` when the chunk has
+    been sent frees the slot (link count back to 1), as on the destination.  A chunk of another length, a reader without the patch, or no free slot: the
+    file is an ordinary file and is read as before."""
+
+    def __init__(self, directory, tag: str, size: int, n_slots: int):
+        self.dir, self.size, self.n = Path(directory), int(size), int(n_slots)
+        assert self.size > 0 and self.n > 0
+        self.paths: List[Path] = []
+        self._maps: List[mmap.mmap] = []
+        self.views: List[np.ndarray] = []
+        self.by_inode: Dict[int, int] = {}
+        self._registered_by = None
+        try:
+            for k in range(self.n):
+                p = self.dir / f"{IN_PREFIX}{tag}_{k}_{self.size}.bin.tmp"      # (invisible to claim_slot until it is complete AND page-locked: register renames it)
+                fd = os.open(p, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o644)
+                self.paths.append(p)
+                try:
+                    os.posix_fallocate(fd, 0, self.size)
+                    mm = mmap.mmap(fd, self.size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+                    self.by_inode[os.fstat(fd).st_ino] = k
+                finally:
+                    os.close(fd)
+                self._maps.append(mm)
+                self.views.append(np.frombuffer(mm, np.uint8))
+        except BaseException:
+            self.close()
+            raise
+
+    def register(self, ctx):
+        """Page-lock every slot through ctx (a context without register_host -- emulator, null device -- needs none), then make the slots visible."""
+        self._registered_by = ctx if hasattr(ctx, "register_host") else None
+        for v in self.views:
+            v[::4096] = 0
+            if self._registered_by is not None:
+                ctx.register_host(v)
+        for k, p in enumerate(self.paths):
+            final = p.with_name(p.name[:-4])
+            os.replace(p, final)
+            self.paths[k] = final
+
+    def view_of(self, st: os.stat_result, nbytes: int) -> Optional[np.ndarray]:
+        """The page-locked bytes behind a chunk file whose stat() is `st`, or None when the file is not (a link to) one of these slots."""
+        k = self.by_inode.get(st.st_ino)
+        if k is None or st.st_size != self.size or nbytes != self.size or st.st_dev != os.stat(self.paths[k]).st_dev:
+            return None
+        return self.views[k]
+
+    def close(self):
+        ctx, self._registered_by = self._registered_by, None
+        for v in self.views:
+            if ctx is not None and hasattr(ctx, "unregister_host"):
+                try:
+                    ctx.unregister_host(v)
+                except Exception:
+                    pass
+        for p in self.paths:
+            try:
+                p.unlink()                     # (a chunk that is still linked keeps the inode and its bytes)
+            except FileNotFoundError:
+                pass
+        self.paths, self.views, self.by_inode = [], [], {}
+        for mm in self._maps:
+            try:
+                mm.close()
+            except (BufferError, ValueError):
+                pass
+        self._maps = []
+
+
+_claim_cache: Dict[Tuple[str, int], Tuple[float, List[str]]] = {}
+
+
+def claim_slot(chunk_path, nbytes: int) -> bool:
+    """Reader side (any process, no state): make `chunk_path` a hard link to a free source slot of exactly `nbytes` bytes; False = there is none (write
+    the file as before).  Lock-free: link, then look at the slot's link count -- 2 means the slot is mine; more means another reader linked it at the
+    same moment: let go and try the next one (whoever saw 2 keeps it; both may let go, and the slot is simply free again).  The caller then writes the
+    chunk with a NON-truncating open."""
+    chunk_path = Path(chunk_path)
+    d = chunk_path.parent
+    key = (str(d), int(nbytes))
+    now = time.monotonic()
+    hit = _claim_cache.get(key)
+    if hit is None or now - hit[0] > 1.0:
+        suffix = f"_{int(nbytes)}.bin"
+        try:
+            names = sorted(n for n in os.listdir(d) if n.startswith(IN_PREFIX) and n.endswith(suffix))
+        except FileNotFoundError:
+            names = []
+        hit = _claim_cache[key] = (now, names)
+    names = hit[1]
+    if not names:
+        return False
+    start = (os.getpid() * 7919 + int(now * 1e6)) % len(names)
+    for j in range(len(names)):
+        p = d / names[(start + j) % len(names)]
+        try:
+            if os.stat(p).st_nlink != 1:
+                continue
+            os.link(p, chunk_path)
+        except FileExistsError:
+            return False                       # the chunk's file is there already (a retry): whatever it is, it is written in place
+        except OSError:
+            continue
+        try:
+            if os.stat(p).st_nlink == 2:
+                return True
+        except OSError:
+            pass
+        try:
+            os.unlink(chunk_path)
+        except OSError:
+            pass
+    return False

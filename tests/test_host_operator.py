@@ -726,6 +726,64 @@ def test_steady_state_e2e_script_with_emulated_device():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["dst_consume"]["chunks_deleted_on_arrival"] == 14 and r["dst_consume"]["hashed_on_the_cpu"] >= 1
+    # ... and with a reader stage inside the timed region that downloads into gpu_compress's page-locked source slots
+    p = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_steady.py"), "--context", "emu", "--chunks", "12", "--chunk-kib", "64",
+                        "--connections", "2", "--max-batch", "4", "--workers", "1", "--src-reader", "slots", "--in-slots", "6"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["verified"] and r["src_reader_writes"]["slots"] >= 6 and r["src_reader_writes"]["slots"] + r["src_reader_writes"]["files"] == 14
+
+
+def test_source_slots_are_claimed_once_each_and_consumed_in_place(tmp_path, monkeypatch):
+    """shm_arena.InSlots / claim_slot (round 6: the source's raw side).  Eight readers race for four slots: every slot ends up with exactly one chunk name,
+    the others get none and write ordinary files; a chunk of another length never takes a slot; the operator hands slot-resident chunks to its context as
+    views of the slot's mapping (no read of the file) and everything still comes out right; deleting the chunk frees the slot."""
+    import threading
+
+    from skyplane_amd.gateway import shm_arena, sidecar
+
+    monkeypatch.setenv("SKYTEST_DEVLOG", str(tmp_path / "dev.log"))
+    size = 96 * 1024
+    store, q_in, q_out, _ = _make_store(tmp_path, 0)
+    op = GatewayHipCompress("gpu_compress_0", "r", q_in, q_out, Event(), Queue(), store, n_processes=1, max_batch=16, max_chunk_bytes=size, device_ids=[0],
+                            context_factory=_arena_factory, in_slots=4, in_slot_chunk_bytes=size, handoff="files")
+    ctx = op._context()
+    ins = op._in_slots(ctx, [size])
+    assert ins is not None and ins.n == 4
+    d = store.get_chunk_file_path("x").parent
+    datas = {uuid.uuid4().hex: synth.gen_text(synth.rng_for(5, k), size if k < 8 else size - 1000).tobytes() for k in range(9)}
+    got = {}
+
+    def reader(cid):
+        path = store.get_chunk_file_path(cid)
+        claimed = shm_arena.claim_slot(path, len(datas[cid]))
+        got[cid] = claimed
+        with open(path, "r+b" if claimed else "wb") as f:
+            f.write(datas[cid])
+
+    ths = [threading.Thread(target=reader, args=(cid,)) for cid in datas]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert sum(got.values()) == 4 and not got[list(datas)[8]]                        # four slots, four winners; the odd length never qualifies
+    assert sorted(os.stat(p).st_nlink for p in d.glob("_inslot_*")) == [2, 2, 2, 2]
+    reqs = [ChunkRequest(chunk=Chunk(src_key=c, dest_key=c, chunk_id=c, chunk_length_bytes=len(b), partition_id="0")) for c, b in datas.items()]
+    handed = []
+    real = ctx.process_batch
+    ctx.process_batch = lambda chunks, **kw: (handed.extend(chunks), real(chunks, **kw))[1]
+    assert op.process_batch(reqs) == [True] * 9 and op._tls.in_slot_hits == 4
+    slot_addrs = {v.ctypes.data for v in ins.views}
+    assert sum(isinstance(c, np.ndarray) and c.ctypes.data in slot_addrs for c in handed) == 4
+    for cid, b in datas.items():
+        assert ref.lz4f_decompress(sidecar.compressed_path(store, cid).read_bytes(), len(b)) == b
+    winner = next(c for c, ok in got.items() if ok)
+    os.unlink(store.get_chunk_file_path(winner))
+    shm_arena._claim_cache.clear()
+    assert shm_arena.claim_slot(store.get_chunk_file_path("again"), size) and not shm_arena.claim_slot(store.get_chunk_file_path("nomore"), size)
+    op.worker_exit(0)
+    op.process_exit(0)
+    assert not list(d.glob("_inslot_*"))
 
 
 def test_lanes_collect_before_a_call(tmp_path):

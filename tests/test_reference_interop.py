@@ -35,6 +35,17 @@ def test_checksum_plumbing_and_planner_patches_run_against_the_reference():
     assert "OK f3 chunks=3 f4 program=read_object_store>gpu_compress>mux_and>mux_or>send" in p.stdout
 
 
+def test_source_raw_side_patch_runs_against_the_reference_reader():
+    """SURVEY 8f item 2, the reader's file write: the reference's GatewayObjStoreReadOperator + POSIXInterface.download_object with
+    the two documented edits applied in memory download chunks INTO gpu_compress's page-locked source slots; the operator consumes them where they lie, an
+    object's short tail stays an ordinary file, a deleted chunk frees its slot (tests/_reference_f2.py)."""
+    from tests.emu import emulib
+    emulib.lib()
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "_reference_f2.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, f"{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
+    assert "OK f2 source slots: 2 chunks consumed in place" in p.stdout
+
+
 @pytest.mark.parametrize("scenario", ["to_reference", "from_reference"])
 def test_interop_with_reference_gateway(scenario):
     from tests.emu import emulib
