@@ -9,7 +9,9 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <mutex>
+#include <unistd.h>
 
 #include "skyhip.h"
 #include "wave.h"
@@ -312,6 +314,7 @@ struct skyhip_ctx {
     std::vector<EvPair> ev_busy, ev_free, ev_open;     // open = begun, not ended yet (returned to ev_free if a call bails out in between)
     skyhip_timing tm;
     char hip_err[256];
+    bool counted = false;         // this context is in g_live_contexts
     long fault_after = -1;        // skyhip_debug_fault: the (n+1)-th checked HIP call from now fails artificially (error-path tests); -1 = off
     uint32_t* d_self = nullptr;
     sky_u64* d_prof = nullptr;   // SKY_PROF builds only
@@ -410,6 +413,26 @@ const char* skyhip_strerror(int code) {
 static thread_local char g_create_err[256] = "";     // what went wrong in the last failed skyhip_create of this thread (there is no context to ask)
 const char* skyhip_last_hip_error(skyhip_ctx* ctx) { return ctx ? ctx->hip_err : g_create_err; }
 
+// Contexts alive in this process.  Every context brings six HIP streams, a process's streams share GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
+// streams that share a queue run one after the other: measured fine for two contexts per process at the default (profiles/r5_operator_lanes.txt: 33.6 / 44.0 /
+// 38.1 Gbit/s through the loopback with 1 / 2 / 3 lanes per worker), bimodal at 8-32 queues (profiles/r5_cdc.txt: 148 / 163 / 252 / 257 ms per step in one call).
+// Nothing can pick a stream's queue from here, but a deployment that lands in a configuration that measured badly is told so, once.
+static std::atomic<int> g_live_contexts{0};
+static std::atomic<int> g_queue_note_said{0};
+static void sky_queue_note(int live) {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int q = (e && atoi(e) > 0) ? atoi(e) : 4;
+    const bool odd_queues = q != 4 && live >= 2, many = live >= 3;
+    if (!(odd_queues || many) || getenv("SKYHIP_QUIET")) return;
+    int said = 0;
+    if (!g_queue_note_said.compare_exchange_strong(said, 1)) return;
+    fprintf(stderr, "[skyhip] pid %d: %d contexts = %d streams on %d hardware queues (GPU_MAX_HW_QUEUES%s): kernels of streams that share a queue run one after the "
+                    "other.  Measured: two contexts per process at the default 4 queues is the stable configuration; %s (profiles/r5_operator_lanes.txt, r5_cdc.txt).  "
+                    "SKYHIP_QUIET=1 silences this note.\n",
+            (int)getpid(), live, 6 * live, q, e ? " from the environment" : " default",
+            odd_queues ? "8-32 queues showed a second, 1.7 x slower mode for compressor + CDC launches" : "a third context mostly queues behind the other two's digest launches");
+}
+
 int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_ctx** out) {
     if (!out || max_batch <= 0 || max_chunk_bytes == 0 || max_chunk_bytes > ((size_t)1 << 30)) return SKYHIP_E_INVAL;
     *out = nullptr;
@@ -466,6 +489,8 @@ int skyhip_create(int device_id, size_t max_chunk_bytes, int max_batch, skyhip_c
     if (rc) { snprintf(g_create_err, sizeof g_create_err, "%s", c->hip_err); skyhip_destroy(c); return rc; }
     g_create_err[0] = 0;
     *out = c;
+    c->counted = true;
+    sky_queue_note(++g_live_contexts);
     return SKYHIP_OK;
 }
 
@@ -480,6 +505,7 @@ static skyhip_ctx* g_frames_owner[64] = {};
 
 void skyhip_destroy(skyhip_ctx* c) {
     if (!c) return;
+    if (c->counted) { c->counted = false; --g_live_contexts; }
     (void)hipSetDevice(c->dev);
     {
         std::lock_guard<std::mutex> lk(g_frames_mu);

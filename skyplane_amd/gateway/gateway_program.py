@@ -32,7 +32,7 @@ class GatewayOperator:
 
 
 class GatewayGpuCompress(GatewayOperator):
-    def __init__(self, num_workers: int = 1, max_batch: int = 32, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
+    def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  dedup_wire: bool = False, dedup_epoch_mb: int = 8192):
         super().__init__("gpu_compress")
         self.num_workers = num_workers      # one forked worker per GPU is the intended setting
@@ -48,7 +48,7 @@ class GatewayGpuCompress(GatewayOperator):
 class GatewayGpuDecompress(GatewayOperator):
     """Destination side: takes the place of GatewayReceive's wait operator when the receiver defers the decode."""
 
-    def __init__(self, num_workers: int = 1, max_batch: int = 32, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False,
+    def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False,
                  dedup_store: str = "memory"):
         super().__init__("gpu_decompress")
         # the in-memory segment store lives in one worker process (its lanes share it); "files" puts it into the chunk directory for several
@@ -66,12 +66,12 @@ def create_operator(op: dict, handle: str, region: str, input_queue, output_queu
 
     if op["op_type"] == "gpu_decompress":
         return GatewayHipDecompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
-                                    error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 32),
+                                    error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 64),
                                     max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, verify_md5=op.get("verify_md5", True),
                                     dedup_store=op.get("dedup_store", "memory"))      # (recipes are recognised by their magic)
     if op["op_type"] != "gpu_compress":
         raise ValueError(f"Unsupported op_type {op['op_type']}")   # same failure mode as gateway_daemon.py:267-268
     return GatewayHipCompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
-                              error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 32),
+                              error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 64),
                               max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, compute_md5=op.get("compute_md5", True), cdc=op.get("cdc", False),
                               dedup=op.get("dedup", False), dedup_wire=op.get("dedup_wire", False), dedup_epoch_bytes=op.get("dedup_epoch_mb", 8192) << 20)

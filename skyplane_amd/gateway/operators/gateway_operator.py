@@ -170,7 +170,7 @@ class GatewayHipCompress(GatewayOperator):
     """
 
     def __init__(self, handle: str, region: str, input_queue: GatewayQueue, output_queue: GatewayQueue, error_event, error_queue: Queue,
-                 chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 32, max_chunk_bytes: int = 64 << 20,
+                 chunk_store: ChunkStore, n_processes: Optional[int] = 1, max_batch: int = 64, max_chunk_bytes: int = 64 << 20,
                  device_ids: Optional[List[int]] = None, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
                  idle_sleep_s: float = 0.001, context_factory: Optional[Callable] = None, pipeline_depth: Optional[int] = None, fill_wait_s: Optional[float] = None,
                  prealloc: bool = False, dedup_wire: bool = False, dedup_epoch_bytes: int = 1 << 30, handoff: str = "arena", arena_slots: int = 0,
