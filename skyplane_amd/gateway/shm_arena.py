@@ -499,6 +499,7 @@ class InSlots:
 
 
 _claim_cache: Dict[Tuple[str, int], Tuple[float, List[str]]] = {}
+_claim_cursor: Dict[Tuple[str, int], int] = {}
 
 
 def claim_slot(chunk_path, nbytes: int) -> bool:
@@ -521,8 +522,12 @@ def claim_slot(chunk_path, nbytes: int) -> bool:
     names = hit[1]
     if not names:
         return False
-    start = (os.getpid() * 7919 + int(now * 1e6)) % len(names)
+    # Slots come free in roughly the order they were taken (chunks are sent in the order they were read), so the search goes on from where this process's last
+    # claim ended: the slot behind it is the one that has been busy longest.  (A random start cost ~n/2 stat() calls per claim once most slots were busy --
+    # with 256 slots that was a third of a reader's time, GPU call r6f.)
+    start = _claim_cursor.get(key, os.getpid() * 7919) % len(names)
     for j in range(len(names)):
+        _claim_cursor[key] = (start + j + 1) % len(names)
         p = d / names[(start + j) % len(names)]
         try:
             if os.stat(p).st_nlink != 1:
