@@ -267,9 +267,16 @@ def main():
     ap.add_argument("--log-dir", default="", help="copy the daemons' full logs (API access lines removed) here when the run fails")
     a = ap.parse_args()
     for port in (DST_API, DST_TLS, SRC_API):    # a daemon left over from an earlier run would silently take our requests
-        with socket.socket() as probe:
-            probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            probe.bind(("127.0.0.1", port))
+        for attempt in range(30):                # (the workers of a run that ended seconds ago may still be on their way out: GPU call r6h)
+            try:
+                with socket.socket() as probe:
+                    probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    probe.bind(("127.0.0.1", port))
+                break
+            except OSError:
+                if attempt == 29:
+                    raise
+                time.sleep(1.0)
     try:
         os.setpgrp()                            # everything forked below is reaped as a group at the end
     except PermissionError:
