@@ -106,6 +106,10 @@ extern "C" __global__ void __launch_bounds__(256) sky_seg_prefix(SkySegPrefixArg
     sky_seg_prefix_body(a, smem);
 }
 extern "C" __global__ void __launch_bounds__(256) sky_seg_desc(SkySegDescArgs a) { sky_seg_desc_body(a); }
+extern "C" __global__ void __launch_bounds__(64) SKY_MD5_KERNEL_ATTR sky_segment_md5x(SkySegMd5Args a) {      // the same digests, rows staged through LDS (gear_kernel.inc)
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SKY_SEGX_LDS];
+    sky_segment_md5x_body(a, smem);
+}
 extern "C" __global__ void __launch_bounds__(64) SKY_MD5_KERNEL_ATTR sky_segment_md5(SkySegMd5Args a) { sky_segment_md5_body(a); }      // <= 128 VGPRs like sky_md5_chunks: runs beside the compressor
 extern "C" __global__ void __launch_bounds__(256) sky_gather_runs(SkyRunArgs a) { sky_gather_runs_body(a); }
 extern "C" __global__ void __launch_bounds__(256) sky_lit_plan(SkyLitArgs a) { sky_lit_plan_body(a); }
@@ -633,8 +637,10 @@ static int sky_process_impl(skyhip_ctx* c, int n, const void* d_in, const uint64
         if (pipe) HIPCHK(c, hipStreamWaitEvent(c->s_cdc, pipe->ev_up[pipe->n_sub - 1], 0));
         EvPair ep;
         if ((rc = ev_begin(c, c->s_cdc, K_CDC, &ep))) return rc;
+        uint64_t in_end = 0;      // one past the last input byte of the call: what the staged segment digests may read up to
+        for (size_t i = 0; i < N; i++) if (c->h_in_off.p[i] + c->h_in_len.p[i] > in_end) in_end = c->h_in_off.p[i] + c->h_in_len.p[i];
         rc = sky_cdc_run(&c->cdc, c->s_cdc, (const uint8_t*)d_in, c->d_in_off.p, c->d_in_len.p, c->h_in_len.p, (uint32_t)N,
-                         (flags & SKYHIP_F_DEDUP) != 0, c->hip_err, sizeof c->hip_err, frames_in_place);
+                         (flags & SKYHIP_F_DEDUP) != 0, c->hip_err, sizeof c->hip_err, frames_in_place, in_end);
         if (rc) return rc;
         if ((rc = ev_end(c, c->s_cdc, ep))) return rc;
 #endif
@@ -1141,10 +1147,15 @@ int skyhip_segment_md5_device(skyhip_ctx* c, size_t nseg, const uint64_t* dev_ad
     HIPCHK(c, hipMemcpyAsync(c->d_sv_total.p, &total, 4, hipMemcpyHostToDevice, c->s_lz4));
     SkySegMd5Args ma;
     ma.in = nullptr; ma.desc = c->d_sv_desc.p; ma.seg_total = c->d_sv_total.p; ma.max_segs = total; ma.fps = c->d_sv_fps.p;
+    uint64_t end = 0;
+    for (size_t i = 0; i < nseg; i++) if (len[i] && dev_addr[i] + len[i] > end) end = dev_addr[i] + len[i];
+    ma.in_end = (const uint8_t*)(uintptr_t)end;                  // nothing past the last byte the caller named is read
     uint64_t waves = (nseg + 255u) / 256u;                       // (a range of at least 256 segments per wavefront, as in sky_cdc_run)
     if (waves > c->cdc.segmd5_grid) waves = c->cdc.segmd5_grid;
     if (waves < 1) waves = 1;
-    hipLaunchKernelGGL(sky_segment_md5, dim3((unsigned)waves), dim3(64), 0, c->s_lz4, ma);
+    if (c->cdc.segmd5_staged < 0) { const char* e = getenv("SKYHIP_SEGMD5_STAGED"); c->cdc.segmd5_staged = e ? (atoi(e) != 0) : SKY_SEGMD5_STAGED_DEFAULT; }
+    if (c->cdc.segmd5_staged) hipLaunchKernelGGL(sky_segment_md5x, dim3((unsigned)waves), dim3(64), 0, c->s_lz4, ma);
+    else hipLaunchKernelGGL(sky_segment_md5, dim3((unsigned)waves), dim3(64), 0, c->s_lz4, ma);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fps, c->d_sv_fps.p, nseg * 16, hipMemcpyDeviceToHost, c->s_lz4));
     HIPCHK(c, hipStreamSynchronize(c->s_lz4));                   // (desc and total live on this function's stack)

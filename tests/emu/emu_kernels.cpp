@@ -165,6 +165,9 @@ static void k_gsel(void* a, uint8_t*) { sky_gear_select_body(*(SkyGearArgs*)a); 
 static void k_segpre(void* a, uint8_t* smem) { sky_seg_prefix_body(*(SkySegPrefixArgs*)a, smem); }
 static void k_segdesc(void* a, uint8_t*) { sky_seg_desc_body(*(SkySegDescArgs*)a); }
 static void k_segmd5(void* a, uint8_t*) { sky_segment_md5_body(*(SkySegMd5Args*)a); }
+static void k_segmd5x(void* a, uint8_t* smem) { sky_segment_md5x_body(*(SkySegMd5Args*)a, smem); }
+static int emu_segmd5_staged = 1;      // which of the library's two segment-digest kernels emu_cdc runs (SKYHIP_SEGMD5_STAGED there)
+extern "C" void emu_set_segmd5_staged(int v) { emu_segmd5_staged = v; }
 static void k_dins(void* a, uint8_t*) { sky_dedup_insert_body(*(SkyDedupArgs*)a); }
 static void k_dres(void* a, uint8_t*) { sky_dedup_resolve_body(*(SkyDedupArgs*)a); }
 static void k_litplan(void* a, uint8_t*) { sky_lit_plan_body(*(SkyLitArgs*)a); }
@@ -204,7 +207,13 @@ long emu_cdc(const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, 
     sa.n_chunks = (uint32_t)n; sa.desc = desc.data(); sa.seg_end = seg_end.data();
     emu_launch((n + 3) / 4, 256, 0, k_segdesc, &sa);
     SkySegMd5Args ma; ma.in = in; ma.desc = desc.data(); ma.seg_total = &seg_prefix[n]; ma.max_segs = slots; ma.fps = fps.data();
-    emu_launch(total > 200u ? 2 : 1, 64, 0, k_segmd5, &ma);      // a persistent grid: every lane walks several segments (two wavefronts when there are enough)
+    {
+        sky_u64 end = 0;      // one past the last input byte: the staged kernel may read a row's last piece up to there (the guard tests put an unmapped page behind it)
+        for (int i = 0; i < n; i++) if (off[i] + len[i] > end) end = off[i] + len[i];
+        ma.in_end = in + end;
+    }
+    if (emu_segmd5_staged) emu_launch(total > 200u ? 2 : 1, 64, SKY_SEGX_LDS, k_segmd5x, &ma);
+    else emu_launch(total > 200u ? 2 : 1, 64, 0, k_segmd5, &ma);      // a persistent grid: every lane walks several segments (two wavefronts when there are enough)
     if (dedup) {
         SkyDedupArgs da; da.key_lo = (sky_u64*)key_lo; da.key_hi = (sky_u64*)key_hi; da.first = (sky_u64*)first; da.slot_mask = (1u << slots_log2) - 1u;
         da.fps = fps.data(); da.seg_total = &seg_prefix[n]; da.max_segs = slots; da.seg_base = seg_base; da.seg_slot = seg_slot.data();

@@ -185,6 +185,12 @@ def gather_runs(src_addrs, dst_addrs, lens):
     lib().emu_gather_runs(src.ctypes.data, dst.ctypes.data, ln.ctypes.data, int(ln.size))
 
 
+def set_segmd5_staged(on):
+    """Which of the library's two segment-digest kernels EmuCdc.run uses: True = sky_segment_md5x (rows staged through LDS: the library's default), False =
+    sky_segment_md5 (every lane streams its own segment; SKYHIP_SEGMD5_STAGED=0)."""
+    lib().emu_set_segmd5_staged(1 if on else 0)
+
+
 def set_link_resolve(on):
     """Which of the library's two ways block-linked frames take in decompress(): True = sky_lz4_resolve + sky_lz4_chain (the library's choice up to
     SKYHIP_LINK_RESOLVE_MAX frames per call), False = sky_lz4_link (larger batches)."""

@@ -36,6 +36,16 @@ def _check(chunks, out, prev_fps=()):
     return allfp
 
 
+
+@pytest.fixture(autouse=True, params=["staged", "lane-streamed"])
+def segment_digest_kernel(request):
+    """The library has two segment-digest kernels (sky_segment_md5x: rows staged through LDS, the default; sky_segment_md5: SKYHIP_SEGMD5_STAGED=0): every test of
+    this file runs through both."""
+    emulib.set_segmd5_staged(request.param == "staged")
+    yield request.param
+    emulib.set_segmd5_staged(True)
+
+
 def test_emu_cdc_matches_spec_and_dedup_persists(small_cases):
     G = ref.gear_table()
     e = emulib.EmuCdc()
