@@ -223,9 +223,13 @@ def _cdc_expect(chunks):
     return cuts, fps
 
 
-def test_cdc_fingerprints_dedup_match_spec(small_cases):
+@pytest.mark.parametrize("segment_kernel", ["staged", "lane-streamed"])
+def test_cdc_fingerprints_dedup_match_spec(small_cases, segment_kernel, monkeypatch):
+    """(through both segment-digest kernels: sky_segment_md5x -- rows staged through LDS, the default -- and sky_segment_md5, SKYHIP_SEGMD5_STAGED=0;
+    a context reads the variable at its first CDC call)"""
     from skyplane_amd import hip_ops
 
+    monkeypatch.setenv("SKYHIP_SEGMD5_STAGED", "1" if segment_kernel == "staged" else "0")
     with hip_ops.SkyHipContext(device_id=0, max_chunk_bytes=8 << 20, max_batch=8) as c:
         flags = hip_ops.F_CDC | hip_ops.F_DEDUP | hip_ops.F_MD5 | hip_ops.F_LZ4
         seen = []
