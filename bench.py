@@ -658,7 +658,7 @@ def main():
                     "bytes_per_input_byte": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"] + extra, 4),
                     "algorithmic_bytes_per_input_byte": round(1.0 + tm.lz4_out_bytes / max(tm.lz4_in_bytes, 1), 4),
                     "parts": {"compressor (measured)": round(t["fetch_bytes_per_input_byte"] + t["write_bytes_per_input_byte"], 4), _md5_part[0]: _md5_part[1],
-                              **({"sky_gear_candidates (512 + 64 bytes per lane)": 1.125, "sky_segment_md5 (one read)": 1.0} if args.cdc else {})},
+                              **({"sky_gear_candidates (512 + 64 bytes per lane)": 1.125, "sky_segment_md5x (one read of every segment byte)": 1.0} if args.cdc else {})},
                     "note": "the digest(s) and the CDC kernels are separate passes over the resident stream by construction: a serial chain per chunk / per segment "
                             "cannot share the compressor's one-block-at-a-time LDS copy"}
         # The STEP's own fraction, next to the dominant kernel's: algorithmic bytes of a step (N + C) over the step's wall time.  With --cdc the step is
@@ -670,7 +670,7 @@ def main():
                                    "frac": round(step_alg / step_s / 1e9 / (HBM_PEAK_GBPS * world), 5),
                                    "kernels_ms_per_step": {kname: round(tm.lz4_ms / args.steps, 3), "sky_md5_chunks": round(tm.md5_ms / args.steps, 3),
                                                            **({"sky_frame_layout": round(tm.layout_ms / args.steps, 3), "sky_frame_gather": round(tm.gather_ms / args.steps, 3)} if not in_place else {}),
-                                                           **({"sky_gear_candidates + sky_gear_select + sky_segment_md5 + sky_dedup_*": round(tm.cdc_ms / args.steps, 3)} if args.cdc else {})},
+                                                           **({"sky_gear_candidates + sky_gear_select + sky_segment_md5x + sky_dedup_*": round(tm.cdc_ms / args.steps, 3)} if args.cdc else {})},
                                    "note": "kernel times are HIP-event spans on their own streams and overlap each other (and, with two steps in flight, the neighbouring step): they do not add up to ms"}
         if args.cdc:
             res["kernels_ms_per_step"]["cdc"] = round(tm.cdc_ms / args.steps, 3)
