@@ -152,7 +152,11 @@ def link_stress_cases():
         chain += bytes(chain[-back:][:n]) + bytes([int(rng.integers(0, 256))])
     chain = bytes(chain)
     straddle = (rng.integers(0, 256, 65_500, dtype=np.uint8).tobytes() + b"Q" * 300) * 3 + bytes(70_000) + many[:50_000]
-    return [many, chain, straddle, many[:70_000] + bytes(100_000) + chain[:70_000]]
+    # a four-byte match behind every literal: ~12 600 matches per 64 KiB block -- more than the 8192 descriptors sky_lz4_resolve holds in registers (the rest it
+    # reads again from memory) and six super-batches of sky_lz4_link
+    dense = np.tile(np.frombuffer(b"abcdX", np.uint8), 40_000).copy()
+    dense[4::5] = rng.integers(0, 256, 40_000, dtype=np.uint8)
+    return [many, chain, straddle, many[:70_000] + bytes(100_000) + chain[:70_000], dense.tobytes()]
 
 
 def test_emu_linked_frames_with_many_and_chained_matches():
