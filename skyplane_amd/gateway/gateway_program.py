@@ -33,8 +33,10 @@ class GatewayOperator:
 
 class GatewayGpuCompress(GatewayOperator):
     def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, compute_md5: bool = True, cdc: bool = False, dedup: bool = False,
-                 dedup_wire: bool = False, dedup_epoch_mb: int = 8192):
+                 dedup_wire: bool = False, dedup_epoch_mb: int = 8192, in_slots: int = 0, in_slot_chunk_mb: int = 0):
         super().__init__("gpu_compress")
+        self.in_slots = in_slots            # page-locked source slot files per worker the reader downloads into (0 = off, needs the reader-side patch)
+        self.in_slot_chunk_mb = in_slot_chunk_mb      # ... of the transfer's chunk size (the planner knows it: multipart_chunk_size_mb); 0 = sized by the first batch
         self.num_workers = num_workers      # one forked worker per GPU is the intended setting
         self.max_batch = max_batch
         self.max_chunk_mb = max_chunk_mb
@@ -49,8 +51,9 @@ class GatewayGpuDecompress(GatewayOperator):
     """Destination side: takes the place of GatewayReceive's wait operator when the receiver defers the decode."""
 
     def __init__(self, num_workers: int = 1, max_batch: int = 64, max_chunk_mb: int = 64, verify_md5: bool = True, dedup_wire: bool = False,
-                 dedup_store: str = "memory"):
+                 dedup_store: str = "memory", dedup_verify: str = "segments"):
         super().__init__("gpu_decompress")
+        self.dedup_verify = dedup_verify    # how a chunk that travelled as a recipe is checked: "segments" (literal segments against their fingerprints) or "chunk" (its own MD5 chain)
         # the in-memory segment store lives in one worker process (its lanes share it); "files" puts it into the chunk directory for several
         self.num_workers = 1 if (dedup_wire and dedup_store == "memory") else num_workers
         self.dedup_wire = dedup_wire
@@ -68,10 +71,12 @@ def create_operator(op: dict, handle: str, region: str, input_queue, output_queu
         return GatewayHipDecompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
                                     error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 64),
                                     max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, verify_md5=op.get("verify_md5", True),
-                                    dedup_store=op.get("dedup_store", "memory"))      # (recipes are recognised by their magic)
+                                    dedup_store=op.get("dedup_store", "memory"), dedup_wire=op.get("dedup_wire", False),
+                                    dedup_verify=op.get("dedup_verify", "segments"))      # (recipes are recognised by their magic; dedup_wire only sets the lanes' defaults)
     if op["op_type"] != "gpu_compress":
         raise ValueError(f"Unsupported op_type {op['op_type']}")   # same failure mode as gateway_daemon.py:267-268
     return GatewayHipCompress(handle=handle, region=region, input_queue=input_queue, output_queue=output_queue, error_event=error_event,
                               error_queue=error_queue, chunk_store=chunk_store, n_processes=op.get("num_workers", 1), max_batch=op.get("max_batch", 64),
                               max_chunk_bytes=op.get("max_chunk_mb", 64) << 20, compute_md5=op.get("compute_md5", True), cdc=op.get("cdc", False),
-                              dedup=op.get("dedup", False), dedup_wire=op.get("dedup_wire", False), dedup_epoch_bytes=op.get("dedup_epoch_mb", 8192) << 20)
+                              dedup=op.get("dedup", False), dedup_wire=op.get("dedup_wire", False), dedup_epoch_bytes=op.get("dedup_epoch_mb", 8192) << 20,
+                              in_slots=op.get("in_slots", 0), in_slot_chunk_bytes=op.get("in_slot_chunk_mb", 0) << 20)
