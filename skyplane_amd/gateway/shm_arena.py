@@ -525,25 +525,30 @@ def claim_slot(chunk_path, nbytes: int) -> bool:
     # Slots come free in roughly the order they were taken (chunks are sent in the order they were read), so the search goes on from where this process's last
     # claim ended: the slot behind it is the one that has been busy longest.  (A random start cost ~n/2 stat() calls per claim once most slots were busy --
     # with 256 slots that was a third of a reader's time, GPU call r6f.)
-    start = _claim_cursor.get(key, os.getpid() * 7919) % len(names)
-    for j in range(len(names)):
-        _claim_cursor[key] = (start + j + 1) % len(names)
-        p = d / names[(start + j) % len(names)]
-        try:
-            if os.stat(p).st_nlink != 1:
+    for _sweep in range(3):                    # (a slot two readers let go of at the same moment is free again: only a sweep that saw a collision is repeated)
+        collided = False
+        start = _claim_cursor.get(key, os.getpid() * 7919) % len(names)
+        for j in range(len(names)):
+            _claim_cursor[key] = (start + j + 1) % len(names)
+            p = d / names[(start + j) % len(names)]
+            try:
+                if os.stat(p).st_nlink != 1:
+                    continue
+                os.link(p, chunk_path)
+            except FileExistsError:
+                return False                   # the chunk's file is there already (a retry): whatever it is, it is written in place
+            except OSError:
                 continue
-            os.link(p, chunk_path)
-        except FileExistsError:
-            return False                       # the chunk's file is there already (a retry): whatever it is, it is written in place
-        except OSError:
-            continue
-        try:
-            if os.stat(p).st_nlink == 2:
-                return True
-        except OSError:
-            pass
-        try:
-            os.unlink(chunk_path)
-        except OSError:
-            pass
+            try:
+                if os.stat(p).st_nlink == 2:
+                    return True
+            except OSError:
+                pass
+            collided = True
+            try:
+                os.unlink(chunk_path)
+            except OSError:
+                pass
+        if not collided:
+            break
     return False

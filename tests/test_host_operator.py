@@ -766,21 +766,26 @@ def test_source_slots_are_claimed_once_each_and_consumed_in_place(tmp_path, monk
         t.start()
     for t in ths:
         t.join()
-    assert sum(got.values()) == 4 and not got[list(datas)[8]]                        # four slots, four winners; the odd length never qualifies
-    assert sorted(os.stat(p).st_nlink for p in d.glob("_inslot_*")) == [2, 2, 2, 2]
+    # never two names on one slot, the odd length never qualifies; normally all four slots are taken (two readers that link one slot at the same moment both let
+    # go, and a sweep that saw a collision is repeated -- a slot left free by three collisions in a row is allowed, a slot with two chunks is not)
+    assert 3 <= sum(got.values()) <= 4 and not got[list(datas)[8]]
+    links = sorted(os.stat(p).st_nlink for p in d.glob("_inslot_*"))
+    assert all(n in (1, 2) for n in links) and links.count(2) == sum(got.values())
     reqs = [ChunkRequest(chunk=Chunk(src_key=c, dest_key=c, chunk_id=c, chunk_length_bytes=len(b), partition_id="0")) for c, b in datas.items()]
     handed = []
     real = ctx.process_batch
     ctx.process_batch = lambda chunks, **kw: (handed.extend(chunks), real(chunks, **kw))[1]
-    assert op.process_batch(reqs) == [True] * 9 and op._tls.in_slot_hits == 4
+    assert op.process_batch(reqs) == [True] * 9 and op._tls.in_slot_hits == sum(got.values())
     slot_addrs = {v.ctypes.data for v in ins.views}
-    assert sum(isinstance(c, np.ndarray) and c.ctypes.data in slot_addrs for c in handed) == 4
+    assert sum(isinstance(c, np.ndarray) and c.ctypes.data in slot_addrs for c in handed) == sum(got.values())
     for cid, b in datas.items():
         assert ref.lz4f_decompress(sidecar.compressed_path(store, cid).read_bytes(), len(b)) == b
     winner = next(c for c, ok in got.items() if ok)
     os.unlink(store.get_chunk_file_path(winner))
     shm_arena._claim_cache.clear()
-    assert shm_arena.claim_slot(store.get_chunk_file_path("again"), size) and not shm_arena.claim_slot(store.get_chunk_file_path("nomore"), size)
+    assert shm_arena.claim_slot(store.get_chunk_file_path("again"), size)
+    if sum(got.values()) == 4:
+        assert not shm_arena.claim_slot(store.get_chunk_file_path("nomore"), size)
     op.worker_exit(0)
     op.process_exit(0)
     assert not list(d.glob("_inslot_*"))
