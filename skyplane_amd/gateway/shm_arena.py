@@ -299,9 +299,9 @@ class LinkSlots:
     the link count of the slot's inode back to 1, which is what marks the slot free: no other IPC.  Chunks of another length (an object's short tail)
     and times when every slot is still waiting for its upload take the plain write path -- slower, never wrong.
 
-    Why only the destination: the source side's ``<id>.chunk`` is created by ``download_object(..., dst_file_path)`` of whichever object-store interface
+    The source side has its own slot files since round 6 (InSlots below) -- behind a two-word change in the reference, because there ``<id>.chunk`` is created by ``download_object(..., dst_file_path)`` of whichever object-store interface
     serves the bucket (s3_interface.py:156-192 and siblings), every one of which opens its destination with mode "wb" -- a truncation, which frees the
-    pages a registration pinned.  Page-locked source chunks would need a change in each interface, outside this path's boundary."""
+    pages a registration pinned (INTEGRATION 6e is the change)."""
 
     def __init__(self, directory, tag: str, size: int, n_slots: int):
         self.dir, self.size, self.n = Path(directory), int(size), int(n_slots)
